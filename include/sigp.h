@@ -1,0 +1,129 @@
+/*
+ * sigp.h -- C ABI of the MI355X-native Gaussian-process engine (libsigp.so).
+ *
+ * Drop-in boundary for the GPR hot path of William-gregory/SeaIceExtentForecasting.  The reference has
+ * no function boundary there: the path is the inline statement block
+ *     north/June1st.py:231-277   (M ... fvar)          and the closure
+ *     north/June1st.py:235-257   MLII(hyperparameters) -> (nlML, grad[2])
+ * repeated byte-identically in all 14 forecast scripts.  Each entry point below cites
+ * the statements it replaces.  Binding on the reference side is ctypes.
+ *
+ * Conventions
+ *   - plain C, no C++ exceptions cross the ABI; every call returns SIGP_OK / SIGP_NOT_SPD /
+ *     SIGP_BAD_ARG / SIGP_HIP_ERROR; message via sigp_last_error().
+ *   - host arrays are row-major float64 (NumPy C order) owned by the caller; the library owns all
+ *     device memory and frees it in sigp_destroy().
+ *   - one handle = one GPU + its streams and workspaces.  Calls on a handle are serialised on its
+ *     streams and are synchronous on return; a handle is NOT thread-safe, distinct handles are
+ *     independent.
+ *   - there is no CPU fallback: without a usable HIP device sigp_create() fails with SIGP_HIP_ERROR.
+ */
+#ifndef SIGP_H
+#define SIGP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sigp_handle sigp_handle;
+
+enum { SIGP_OK = 0, SIGP_NOT_SPD = 1, SIGP_BAD_ARG = 2, SIGP_HIP_ERROR = 3 };
+enum { SIGP_F64 = 0, SIGP_F32 = 1 };
+/* covariance functions: 0 is the reference's own (north/June1st.py:264-265); 1,2 are the kernels
+ * BASELINE.json's configs add on the same fit/solve/predict skeleton. */
+enum { SIGP_KERNEL_NETDIFFUSION = 0, SIGP_KERNEL_RBF = 1, SIGP_KERNEL_MATERN52 = 2 };
+/* sigp_get_matrix selectors */
+enum { SIGP_MAT_K = 0, SIGP_MAT_L = 1 };
+/* kernel classes for sigp_profile_get */
+enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_INNER = 3,
+       SIGP_KC_UPDATE_OUTER = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_COUNT = 6 };
+
+#define SIGP_MAX_RIDE 127 /* test points that can ride along one factorisation */
+
+int sigp_version(void);
+
+/* lifetime ------------------------------------------------------------------------------------ */
+int sigp_create(sigp_handle** h, int device_id, int dtype);
+int sigp_destroy(sigp_handle* h);
+const char* sigp_last_error(const sigp_handle* h);
+
+/* data staging: the enclosing-scope variables the reference block reads ------------------------- */
+/* X [n,d] (row stride ldx), y [n]:  north/June1st.py:214, 226-229 (y, X).  Copies host -> HBM. */
+int sigp_set_train(sigp_handle* h, const double* X, int64_t n, int64_t d, int64_t ldx, const double* y);
+/* Xs [m,d], m <= SIGP_MAX_RIDE: the test row(s) north/June1st.py:228 (Xs).  These "ride along" the
+ * factorisation as extra right-hand-side rows, so fit+predict needs no separate triangular solve.
+ * m = 0 clears them. */
+int sigp_set_test(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs);
+
+/* K5: kernel-matrix build  K~ = k(X,X) + sn_tilde*I  into HBM (lower triangle), plus the ride-along
+ * rows [y ; k~(Xs,X)].  Replaces north/June1st.py:265 (the multi_dot + eye term).
+ * RBF / Matern-5/2: ell is the length scale.  */
+int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde);
+/* Reference kernel: host passes Sigma~ = expm(ell*M) [N,N] (north/June1st.py:264; N = d of set_train);
+ * device forms X Sigma~ X^T + sn_tilde*I (north/June1st.py:265). */
+int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde);
+
+/* K6: blocked Cholesky  K~ = L~ L~^T  in place (north/June1st.py:265 np.linalg.cholesky).
+ * info: 0, or LAPACK-style 1-based index of the first non-positive pivot (-> SIGP_NOT_SPD). */
+int sigp_potrf(sigp_handle* h, int64_t* info);
+
+/* K7,K8,K12: A~ = K~^-1 y, sigma_f = y^T A~/n (north/June1st.py:266-268), nlML (north/June1st.py:246).
+ * Requires sigp_potrf. */
+int sigp_fit(sigp_handle* h, double* sigma_f, double* nlml);
+
+/* K9-K11 for the ride-along test rows: mean[m], var[m] (var includes sigma_n: north/June1st.py:272-277). */
+int sigp_predict_ride(sigp_handle* h, double* mean, double* var);
+/* K9-K11 for arbitrary new test points after a fit (any m): cross-kernel build + forward solve. */
+int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, double* mean, double* var);
+
+/* Fused hot path: build -> potrf -> fit -> predict_ride with one host synchronisation.
+ * Sigma may be NULL unless kernel_id == SIGP_KERNEL_NETDIFFUSION.
+ * out[4] = { sigma_f, nlml, (double)info, sigma_n };  mean/var [m_ride] may be NULL when m_ride == 0. */
+int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma,
+                     int64_t ldsigma, double* out, double* mean, double* var);
+
+/* Batch of independent fits that share (n, d, m): the retrospective loop over years
+ * (north/retrospective_forecasts/September1st_retro.py:176-248) and the hyper-parameter grid
+ * (north/June1st.py:210-211).  Problem b uses X + b*strideX, y + b*stridey, Xs + b*strideXs
+ * (a stride of 0 shares the array between problems, e.g. one data set x many grid points).
+ * RBF / Matern only.  out [batch,4], mean/var [batch,m].  Fits are pipelined over `concurrency`
+ * stream sets (1..8) so one fit's panel factorisations overlap another's trailing updates. */
+int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X, int64_t strideX,
+                   const double* y, int64_t stridey, const double* Xs, int64_t strideXs, int64_t n,
+                   int64_t d, int64_t m, const double* ell, const double* sn_tilde, int concurrency,
+                   double* out, double* mean, double* var);
+/* Same, with every input already resident in HBM (device pointers, same layout/strides):
+ * the timed region of bench.py starts here. */
+int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t strideX, const double* y,
+                      int64_t stridey, const double* Xs, int64_t strideXs, int64_t n, int64_t d, int64_t m);
+int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* ell,
+                   const double* sn_tilde, int concurrency, double* out, double* mean, double* var);
+
+/* K7 (explicit): alpha~ = K~^-1 y  [n]  (north/June1st.py:266; alpha of :271 is alpha~/sigma_f). */
+int sigp_get_alpha(sigp_handle* h, double* alpha_tilde);
+/* copy the lower triangle of K~ (before potrf) or L~ (after) to host, [n,n] row-major, upper = 0 */
+int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo);
+
+/* K13/K14: MLII(theta) (north/June1st.py:235-257): theta = (log ell, log sn_tilde).
+ * grad_mode 0 = none, 1 = reference formulae (:248-252), 2 = exact derivative of the profiled nlML.
+ * Non-SPD -> returns SIGP_NOT_SPD and nlml = grad = +inf (the reference's except branch :254-256).
+ * For the reference kernel the caller passes Sigma~ and dSigma = M @ Sigma~ (host, [N,N]). */
+int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma,
+                   const double* MSigma, int64_t ldsigma, int grad_mode, double* nlml, double grad[2]);
+
+/* measurement ---------------------------------------------------------------------------------- */
+/* enable=1: bracket every kernel launch with HIP events on the stream it is launched on and
+ * accumulate per kernel class; enable=0: off (default).  sigp_profile_get drains finished events. */
+int sigp_profile(sigp_handle* h, int enable);
+int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* launches, double* flops,
+                     double* bytes);
+int sigp_profile_reset(sigp_handle* h);
+/* tuning knobs (block widths in units of 128 columns, look-ahead on/off); returns SIGP_BAD_ARG if invalid */
+int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGP_H */

@@ -1,0 +1,12 @@
+"""MI355X-native Gaussian-process engine for the GPR hot path of SeaIceExtentForecasting.
+
+Host side of the drop-in boundary: ``GPR.fit / predict / nlml / fit_batch / nlml_grid``
+over hand-written HIP kernels behind a C ABI (include/sigp.h, libsigp.so).  There is no CPU fallback.
+"""
+from .gpr import GPR, LinAlgError  # noqa: F401
+from .features import (SCRIPT_TABLE, LGRID, SGRID, select_features, design_matrix, laplacian_M,  # noqa: F401
+                       sigma_tilde)
+from .retro import retro_forecast, operational_forecast  # noqa: F401
+
+__all__ = ["GPR", "LinAlgError", "SCRIPT_TABLE", "LGRID", "SGRID", "select_features", "design_matrix",
+           "laplacian_M", "sigma_tilde", "retro_forecast", "operational_forecast"]

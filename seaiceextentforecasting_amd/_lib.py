@@ -1,0 +1,82 @@
+"""ctypes binding of libsigp.so (include/sigp.h).  No CPU fallback: if the HIP library is missing or no
+MI355X is visible, importing is fine but creating an engine raises -- the product path never routes
+through NumPy."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsigp.so")
+
+OK, NOT_SPD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
+KERNEL_IDS = {"netdiffusion": 0, "rbf": 1, "matern52": 2}
+KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_inner": 3, "update_outer": 4, "epilogue": 5}
+MAX_RIDE = 127
+
+_dp = C.POINTER(C.c_double)
+_i64 = C.c_int64
+_h = C.c_void_p
+
+# every symbol include/sigp.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "sigp_version": (C.c_int, []),
+    "sigp_create": (C.c_int, [C.POINTER(_h), C.c_int, C.c_int]),
+    "sigp_destroy": (C.c_int, [_h]),
+    "sigp_last_error": (C.c_char_p, [_h]),
+    "sigp_set_train": (C.c_int, [_h, _dp, _i64, _i64, _i64, _dp]),
+    "sigp_set_test": (C.c_int, [_h, _dp, _i64, _i64]),
+    "sigp_kernel_build": (C.c_int, [_h, C.c_int, C.c_double, C.c_double]),
+    "sigp_kernel_build_from_sigma": (C.c_int, [_h, _dp, _i64, C.c_double]),
+    "sigp_potrf": (C.c_int, [_h, C.POINTER(_i64)]),
+    "sigp_fit": (C.c_int, [_h, _dp, _dp]),
+    "sigp_predict_ride": (C.c_int, [_h, _dp, _dp]),
+    "sigp_predict": (C.c_int, [_h, _dp, _i64, _i64, _dp, _dp]),
+    "sigp_fit_predict": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, _dp, _i64, _dp, _dp, _dp]),
+    "sigp_fit_batch": (C.c_int, [_h, _i64, C.c_int, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dp, _dp,
+                                 C.c_int, _dp, _dp, _dp]),
+    "sigp_batch_upload": (C.c_int, [_h, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64]),
+    "sigp_batch_run": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
+    "sigp_get_alpha": (C.c_int, [_h, _dp]),
+    "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
+    "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, _dp, _dp]),
+    "sigp_profile": (C.c_int, [_h, C.c_int]),
+    "sigp_profile_get": (C.c_int, [_h, C.c_int, _dp, C.POINTER(_i64), _dp, _dp]),
+    "sigp_profile_reset": (C.c_int, [_h]),
+    "sigp_set_option": (C.c_int, [_h, C.c_char_p, _i64]),
+}
+
+_lib = None
+
+
+class SigpError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libsigp.so and bind every declared symbol.  Fails loudly when the HIP build is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SigpError("libsigp.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C seaiceextentforecasting_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def f64(a, ndim=None):
+    """C-contiguous float64 copy/view (the reference's X is a transposed view: SURVEY App. C-8)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError("expected %d-D array, got shape %s" % (ndim, a.shape))
+    return a

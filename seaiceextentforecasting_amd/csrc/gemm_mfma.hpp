@@ -1,0 +1,176 @@
+// fp64 MFMA tile GEMM for gfx950:  C (-)= A * B^T  (or A * B), the kernel behind
+//   - the panel TRSM            L21 = A21 * inv(L11)^T        (north/June1st.py:265 np.linalg.cholesky)
+//   - the inner / outer trailing updates  A22 -= L21 L21^T     (same call; >99 % of the flops)
+//   - the forward / backward block solves of predict and alpha (north/June1st.py:266, 274)
+//   - the reference kernel build  X Sigma X^T                  (north/June1st.py:265 multi_dot)
+//
+// Design (CDNA4): 256 threads = 4 waves; each wave owns a (TM/WM)x(TN/WN) register tile made of
+// 16x16 v_mfma_f64_16x16x4_f64 accumulators.  A and B tiles are staged global -> VGPR -> LDS in
+// K-slices of 16 with one barrier per slice (double buffered); the LDS images are [row][k] with a
+// pitch of 18 doubles so that the per-lane 8-byte fragment reads (row = lane&15, k = lane>>4) hit 32
+// distinct 8-byte bank slots per 32-lane group (conflict free).  Subtraction is folded into the A
+// staging (A is negated once on its way to LDS) so the accumulator is initialised from C and written
+// back once: C traffic is one read + one write per tile, whatever K is.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sigp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+constexpr int KT = 16;        // k-slice per LDS stage
+constexpr int LDP = KT + 2;   // LDS pitch (doubles) of a [row][k] image
+
+enum { GEMM_SUB = 0, GEMM_SET = 1 };
+
+struct GemmArgs {
+  const double* A; long lda;   // A is M x K row-major (K contiguous)
+  const double* B; long ldb;   // B is N x K row-major (BT=false) or K x N row-major (BT=true)
+  double* C; long ldc;
+  int K;                       // multiple of 16
+  // tile space in units of (TM, TN): columns bj in [c0,c1), rows bi in [max(r0, lower ? bj : r0), r1)
+  int r0, r1, c0, c1;
+  int lower;
+};
+
+// number of tiles of the (possibly trapezoidal) tile space; shared by host and device
+__host__ __device__ inline int gemm_tile_count(int r0, int r1, int c0, int c1, int lower) {
+  if (r1 <= r0 || c1 <= c0) return 0;
+  if (!lower) return (r1 - r0) * (c1 - c0);
+  int n = 0;
+  for (int c = c0; c < c1; ++c) { int lo = c > r0 ? c : r0; if (r1 > lo) n += r1 - lo; }
+  return n;
+}
+
+__device__ inline bool gemm_tile_coords(const GemmArgs& g, int b, int& bi, int& bj) {
+  if (!g.lower) {
+    int nr = g.r1 - g.r0;
+    bj = g.c0 + b / nr;
+    bi = g.r0 + b % nr;
+    return bj < g.c1;
+  }
+  int rem = b;
+  for (int c = g.c0; c < g.c1; ++c) {
+    int lo = c > g.r0 ? c : g.r0;
+    int cnt = g.r1 - lo;
+    if (cnt <= 0) continue;
+    if (rem < cnt) { bj = c; bi = lo + rem; return true; }
+    rem -= cnt;
+  }
+  return false;
+}
+
+template <int TM, int TN, bool BT>
+constexpr int gemm_lds_bytes() {
+  return (2 * TM * LDP + (BT ? 2 * KT * (TN + 16) : 2 * TN * LDP)) * (int)sizeof(double);
+}
+
+template <int TM, int TN, int WM, int WN, int MODE, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int WTM = TM / WM, WTN = TN / WN;
+  constexpr int FM = WTM / 16, FN = WTN / 16;
+  constexpr int PA = TM / 32;   // d2 loads per thread per stage for A (TM rows x 16 k = TM*8 d2)
+  constexpr int PB = TN / 32;
+  constexpr int BTP = TN + 16;  // pitch of the [k][n] image (BT)
+  static_assert(FM >= 1 && FN >= 1 && PA >= 1 && PB >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* As = smem;                  // [2][TM][LDP]
+  double* Bs = smem + 2 * TM * LDP;   // [2][TN][LDP]  or  [2][KT][BTP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  int bi, bj;
+  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
+  const double* Ag = g.A + (long)bi * TM * g.lda;
+  const double* Bg = BT ? g.B + (long)bj * TN : g.B + (long)bj * TN * g.ldb;
+  double* Cg = g.C + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
+
+  d4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      if (MODE == GEMM_SUB) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr];
+      } else {
+        acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+      }
+    }
+
+  // staging coordinates
+  const int arow = tid >> 3, acp = (tid & 7) * 2;                 // [row][k] images: 8 lanes per 128-B row
+  constexpr int BT_TPR = TN / 2;                                   // threads per k-row of the [k][n] image
+  const int bkr = tid / BT_TPR, bcp = (tid % BT_TPR) * 2;
+  constexpr int BT_RPP = 256 / BT_TPR;                             // k-rows per pass
+
+  d2 va[PA], vb[PB];
+#define SIGP_GLOAD(k0)                                                                         \
+  {                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < PA; ++p)                                             \
+        va[p] = *(const d2*)(Ag + (long)(arow + 32 * p) * g.lda + (k0) + acp);                 \
+    if (BT) {                                                                                  \
+      _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
+          vb[p] = *(const d2*)(Bg + (long)((k0) + bkr + BT_RPP * p) * g.ldb + bcp);            \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
+          vb[p] = *(const d2*)(Bg + (long)(arow + 32 * p) * g.ldb + (k0) + acp);               \
+    }                                                                                          \
+  }
+#define SIGP_SSTORE(buf)                                                                       \
+  {                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                           \
+      d2 t = va[p];                                                                            \
+      if (MODE == GEMM_SUB) t = -t;                                                            \
+      *(d2*)(As + ((buf) * TM + arow + 32 * p) * LDP + acp) = t;                               \
+    }                                                                                          \
+    if (BT) {                                                                                  \
+      _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
+          *(d2*)(Bs + ((buf) * KT + bkr + BT_RPP * p) * BTP + bcp) = vb[p];                    \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
+          *(d2*)(Bs + ((buf) * TN + arow + 32 * p) * LDP + acp) = vb[p];                       \
+    }                                                                                          \
+  }
+
+  const int nst = g.K / KT;
+  SIGP_GLOAD(0);
+  SIGP_SSTORE(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nst) SIGP_GLOAD((s + 1) * KT);
+    const double* Ab = As + (buf * TM + wm * WTM + lr) * LDP + lq;
+    const double* Bb = BT ? Bs + (buf * KT + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDP + lq;
+#pragma unroll
+    for (int kk = 0; kk < KT / 4; ++kk) {
+      double a[FM], b[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) a[i] = Ab[i * 16 * LDP + kk * 4];
+#pragma unroll
+      for (int j = 0; j < FN; ++j) b[j] = BT ? Bb[kk * 4 * BTP + j * 16] : Bb[j * 16 * LDP + kk * 4];
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < nst) SIGP_SSTORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef SIGP_GLOAD
+#undef SIGP_SSTORE
+
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr] = acc[i][j][r];
+}
+
+}  // namespace sigp

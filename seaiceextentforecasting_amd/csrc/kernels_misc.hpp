@@ -1,0 +1,174 @@
+// HBM-bound kernels around the factorisation: covariance build (K5), ride-along rows (K9), fused
+// reductions (K8, K11, K12).  fp64 throughout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "gemm_mfma.hpp"
+
+namespace sigp {
+
+enum { KID_NETDIFFUSION = 0, KID_RBF = 1, KID_MATERN52 = 2 };
+
+struct KParams {
+  int kernel_id;
+  double c_rbf;     // -0.5 / ell^2
+  double inv_ell;   // 1 / ell
+  double sn;        // sigma_n tilde (added on the diagonal)
+};
+
+__device__ inline double cov_from_sq(const KParams& kp, double sq) {
+  if (kp.kernel_id == KID_RBF) return exp(kp.c_rbf * sq);
+  const double s = sqrt(5.0 * sq) * kp.inv_ell;
+  return (1.0 + s + s * s * (1.0 / 3.0)) * exp(-s);
+}
+
+// K5 (north/June1st.py:265 with an RBF / Matern-5/2 covariance in place of X Sigma X^T):
+// lower 64x64 tiles of K~ = k(X,X) + sn I, identity on the padding rows/cols (i or j >= n).
+// X is [n_pad][dp] row-major, zero padded.  Each wave writes two 512-B row segments per store (16 B per lane).
+constexpr int KB_T = 64;    // tile
+constexpr int KB_DC = 32;   // feature chunk staged in LDS
+__global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, int dp, int d, int n,
+                                                     double* __restrict__ Mat, long ld, KParams kp) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  __shared__ double Xi[KB_T][KB_DC + 1];
+  __shared__ __attribute__((aligned(16))) double XjT[KB_DC][KB_T + 2];
+  const int tid = threadIdx.x;
+  const int c2 = (tid & 31) * 2, rg = tid >> 5;
+  double acc[8][2];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) acc[s][0] = acc[s][1] = 0.0;
+  for (int p0 = 0; p0 < d; p0 += KB_DC) {
+    const int pc = min(KB_DC, d - p0);
+    __syncthreads();
+    for (int idx = tid; idx < KB_T * KB_DC; idx += 256) {
+      const int r = idx / KB_DC, p = idx % KB_DC;
+      double vi = 0.0, vj = 0.0;
+      if (p < pc) {
+        vi = X[(long)(bi * KB_T + r) * dp + p0 + p];
+        vj = X[(long)(bj * KB_T + r) * dp + p0 + p];
+      }
+      Xi[r][p] = vi;
+      XjT[p][r] = vj;
+    }
+    __syncthreads();
+    for (int p = 0; p < pc; ++p) {
+      const d2 b = *(const d2*)(&XjT[p][c2]);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const double a = Xi[rg + 8 * s][p];
+        const double d0 = a - b.x, d1 = a - b.y;
+        acc[s][0] += d0 * d0;
+        acc[s][1] += d1 * d1;
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int gi = bi * KB_T + rg + 8 * s, gj = bj * KB_T + c2;
+    d2 v;
+    if (gi >= n) {
+      v.x = (gi == gj) ? 1.0 : 0.0;
+      v.y = (gi == gj + 1) ? 1.0 : 0.0;
+    } else {
+      v.x = (gj < n) ? cov_from_sq(kp, acc[s][0]) + (gi == gj ? kp.sn : 0.0) : 0.0;
+      v.y = (gj + 1 < n) ? cov_from_sq(kp, acc[s][1]) + (gi == gj + 1 ? kp.sn : 0.0) : 0.0;
+    }
+    *(d2*)(Mat + (long)gi * ld + gj) = v;
+  }
+}
+
+// Ride-along block (128 rows x n_pad): row 0 = y (may be null -> zeros), rows 1..m = k~(xs_j, x_i)
+// (north/June1st.py:272 KXXs^T in unit signal variance), remaining rows 0.  first_row lets predict()
+// fill rows 0..m-1 with cross-covariances only (y == nullptr, first_row = 0).
+__global__ __launch_bounds__(256) void ride_build_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
+                                                         const double* __restrict__ y, int dp, int d, int n, int n_pad,
+                                                         int m, int first_row, double* __restrict__ Z, long ld,
+                                                         KParams kp, int compute_cov) {
+  const int i = blockIdx.x * 256 + threadIdx.x;   // column (training point)
+  const int r = blockIdx.y;                       // row of the ride block
+  if (i >= n_pad) return;
+  double v = 0.0;
+  if (i < n) {
+    if (y != nullptr && r == 0) {
+      v = y[i];
+    } else if (compute_cov && r >= first_row && r < first_row + m) {
+      const double* xs = Xs + (long)(r - first_row) * dp;
+      const double* xi = X + (long)i * dp;
+      double sq = 0.0;
+      for (int p = 0; p < d; ++p) { const double t = xs[p] - xi[p]; sq += t * t; }
+      v = cov_from_sq(kp, sq);
+    } else if (!compute_cov) {
+      return;   // rows were produced by a GEMM (reference kernel); only row 0 / padding handled here
+    }
+  }
+  Z[(long)r * ld + i] = v;
+}
+
+// after a GEMM-form build (reference kernel): add sn on the diagonal, identity on the padding
+__global__ void diag_fix_kernel(double* __restrict__ Mat, long ld, int n, int n_pad, double sn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  if (i < n) Mat[(long)i * ld + i] += sn; else Mat[(long)i * ld + i] = 1.0;
+}
+
+// zero-padded copy  dst[rows_pad][dp] <- src[rows][d] (row stride lds)
+__global__ void pad_copy_kernel(const double* __restrict__ src, long lds, int rows, int d, double* __restrict__ dst,
+                                int rows_pad, int dp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows_pad * dp) return;
+  const int r = (int)(idx / dp), p = (int)(idx % dp);
+  dst[idx] = (r < rows && p < d) ? src[(long)r * lds + p] : 0.0;
+}
+
+__device__ inline double block_reduce_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+  return t;   // valid on thread 0
+}
+
+// K8/K11/K12 fused reductions over the solved ride rows W = [z ; v_1..v_m] (z = L~^-1 y, v = L~^-1 k~*):
+//   res[r]       = W[r] . zrow      (r = 0: y^T A~ = n sigma_f, north/June1st.py:267;  r>0: fmean, :276)
+//   res[128 + r] = W[r] . W[r]      (v^T v of north/June1st.py:277)
+//   res[256]     = sum_i<n log L~_ii (north/June1st.py:246)
+// grid = nrows + 1 blocks of 256 threads.
+__global__ __launch_bounds__(256) void epilogue_kernel(const double* __restrict__ W, long ldw, const double* __restrict__ zrow,
+                                                       const double* __restrict__ Mat, long ld, int n, int n_pad, int nrows,
+                                                       double* __restrict__ res) {
+  __shared__ double sh[4];
+  const int r = blockIdx.x;
+  if (r < nrows) {
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < n_pad; i += 256) {
+      const double w = W[(long)r * ldw + i];
+      a += w * zrow[i];
+      b += w * w;
+    }
+    a = block_reduce_sum(a, sh);
+    b = block_reduce_sum(b, sh);
+    if (threadIdx.x == 0) { res[r] = a; res[128 + r] = b; }
+  } else if (Mat != nullptr) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += log(Mat[(long)i * ld + i]);
+    a = block_reduce_sum(a, sh);
+    if (threadIdx.x == 0) res[256] = a;
+  }
+}
+
+// copy a [rows][cols] block (device -> device) with different strides
+__global__ void copy_block_kernel(const double* __restrict__ src, long lds, double* __restrict__ dst, long ldd, int rows,
+                                  int cols) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx % cols);
+  dst[(long)r * ldd + c] = src[(long)r * lds + c];
+}
+
+}  // namespace sigp

@@ -1,0 +1,911 @@
+// libsigp.so -- C-ABI + host-side drivers of the MI355X-native GP engine (see include/sigp.h).
+// Device code: gemm_mfma.hpp (fp64 MFMA tile GEMM), potrf_diag.hpp (diagonal block), kernels_misc.hpp.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/sigp.h"
+#include "gemm_mfma.hpp"
+#include "kernels_misc.hpp"
+#include "potrf_diag.hpp"
+
+using namespace sigp;
+
+namespace {
+
+constexpr int NB = 128;         // column-block width of the factorisation (= diagonal block)
+constexpr int RIDE = 128;       // rows of the ride-along block
+constexpr int MAX_SLOTS = 8;
+
+struct ProfEvent { hipEvent_t a, b; int kclass; };
+
+// One "slot" = everything one in-flight fit needs: the augmented matrix, inverse diagonal blocks, two
+// streams (update / panel) and result buffers.  Slot 0 backs the single-fit API.
+struct Slot {
+  double* mat = nullptr;      // [(n_pad + RIDE)][n_pad]: K~ -> L~ (lower) and the ride rows below it
+  double* dinv = nullptr;     // [T][128][128] inverses of the diagonal blocks
+  double* res = nullptr;      // device [512]: epilogue reductions
+  double* res_host = nullptr; // pinned [512]
+  int* info = nullptr;        // device
+  int* info_host = nullptr;   // pinned
+  long cap_npad = 0;
+  hipStream_t s_upd = nullptr, s_pan = nullptr;
+  hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
+};
+
+}  // namespace
+
+struct sigp_handle {
+  int device = 0;
+  int dtype = SIGP_F64;
+  std::string err;
+  // problem
+  long n = 0, d = 0, dp = 0, n_pad = 0, m = 0;
+  double* X = nullptr;  long cap_X = 0;       // [n_pad][dp]
+  double* y = nullptr;  long cap_y = 0;       // [n_pad]
+  double* Xs = nullptr; long cap_Xs = 0;      // [128][dp] ride-along test rows (row j = test point j)
+  double* scratchZ = nullptr; long cap_Z = 0; // [128][n_pad] second ride block (predict / alpha)
+  double* T = nullptr; long cap_T = 0;        // reference kernel: X Sigma~ [n_pad][dp]
+  double* Sig = nullptr; long cap_Sig = 0;    // Sigma~ padded [dp][dp]
+  double* XsA = nullptr;                      // [128][dp] ride rows shifted by one (row 0 = 0) for the GEMM-form build
+  double* stage = nullptr; long cap_stage = 0;// generic host->device staging
+  std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
+  std::vector<double> fit_res;                // epilogue reductions of the last fit (host copy)
+  Slot slots[MAX_SLOTS];
+  int nslots = 0;
+  // batch data (device resident)
+  double* bX = nullptr; double* by = nullptr; double* bXs = nullptr;
+  long b_count = 0, b_n = 0, b_d = 0, b_dp = 0, b_m = 0, b_npad = 0;
+  // state
+  int kernel_id = -1;
+  double ell = 0, sn_tilde = 0;
+  bool built = false, factored = false, fitted = false;
+  double sigma_f = 0, nlml = 0;
+  KParams kp{};
+  // options
+  int opt_outer = 2;       // outer panel width in 128-blocks
+  int opt_lookahead = 1;
+  int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
+  // profiling
+  bool prof = false;
+  std::vector<ProfEvent> pev;
+  double p_ms[SIGP_KC_COUNT] = {0};
+  int64_t p_n[SIGP_KC_COUNT] = {0};
+  double p_flops[SIGP_KC_COUNT] = {0};
+  double p_bytes[SIGP_KC_COUNT] = {0};
+};
+
+namespace {
+
+int fail(sigp_handle* h, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                              \
+  do {                                                                                               \
+    hipError_t e_ = (expr);                                                                          \
+    if (e_ != hipSuccess)                                                                            \
+      return fail(h, SIGP_HIP_ERROR, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+int ensure(sigp_handle* h, double** p, long* cap, long need) {
+  if (*cap >= need) return SIGP_OK;
+  if (*p) HIPCHK(h, hipFree(*p));
+  *p = nullptr; *cap = 0;
+  HIPCHK(h, hipMalloc((void**)p, (size_t)need * sizeof(double)));
+  *cap = need;
+  return SIGP_OK;
+}
+
+int slot_init(sigp_handle* h, Slot& s) {
+  if (s.s_upd) return SIGP_OK;
+  int lo = 0, hi = 0;
+  HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+  HIPCHK(h, hipStreamCreateWithPriority(&s.s_upd, hipStreamNonBlocking, lo));
+  HIPCHK(h, hipStreamCreateWithPriority(&s.s_pan, hipStreamNonBlocking, hi));
+  HIPCHK(h, hipEventCreateWithFlags(&s.ev_pan, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&s.ev_la, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  HIPCHK(h, hipMalloc((void**)&s.res, 512 * sizeof(double)));
+  HIPCHK(h, hipHostMalloc((void**)&s.res_host, 512 * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&s.info, sizeof(int)));
+  HIPCHK(h, hipHostMalloc((void**)&s.info_host, sizeof(int)));
+  return SIGP_OK;
+}
+
+int slot_reserve(sigp_handle* h, Slot& s, long n_pad) {
+  int rc = slot_init(h, s);
+  if (rc) return rc;
+  if (s.cap_npad >= n_pad) return SIGP_OK;
+  if (s.mat) HIPCHK(h, hipFree(s.mat));
+  if (s.dinv) HIPCHK(h, hipFree(s.dinv));
+  s.mat = nullptr; s.dinv = nullptr; s.cap_npad = 0;
+  HIPCHK(h, hipMalloc((void**)&s.mat, (size_t)(n_pad + RIDE) * n_pad * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&s.dinv, (size_t)(n_pad / NB) * NB * NB * sizeof(double)));
+  s.cap_npad = n_pad;
+  return SIGP_OK;
+}
+
+void slot_free(Slot& s) {
+  if (s.mat) (void)hipFree(s.mat);
+  if (s.dinv) (void)hipFree(s.dinv);
+  if (s.res) (void)hipFree(s.res);
+  if (s.res_host) (void)hipHostFree(s.res_host);
+  if (s.info) (void)hipFree(s.info);
+  if (s.info_host) (void)hipHostFree(s.info_host);
+  if (s.ev_pan) (void)hipEventDestroy(s.ev_pan);
+  if (s.ev_la) (void)hipEventDestroy(s.ev_la);
+  if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  if (s.s_upd) (void)hipStreamDestroy(s.s_upd);
+  if (s.s_pan) (void)hipStreamDestroy(s.s_pan);
+  s = Slot();
+}
+
+// ---- profiling brackets -------------------------------------------------------------------------
+struct ProfScope {
+  sigp_handle* h; hipStream_t st; ProfEvent pe; bool on;
+  ProfScope(sigp_handle* h_, hipStream_t st_, int kclass, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+    h->p_flops[kclass] += flops; h->p_bytes[kclass] += bytes; h->p_n[kclass] += 1;
+    if (on) {
+      pe.kclass = kclass;
+      (void)hipEventCreate(&pe.a); (void)hipEventCreate(&pe.b);
+      (void)hipEventRecord(pe.a, st);
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(pe.b, st); h->pev.push_back(pe); }
+  }
+};
+
+void prof_drain(sigp_handle* h) {
+  for (auto& pe : h->pev) {
+    (void)hipEventSynchronize(pe.b);
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) h->p_ms[pe.kclass] += ms;
+    (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b);
+  }
+  h->pev.clear();
+}
+
+// ---- GEMM launch ----------------------------------------------------------------------------------
+template <int TM, int TN, int WM, int WN, int MODE, bool BT>
+int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
+  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
+  if (nt <= 0) return SIGP_OK;
+  auto kern = gemm_mfma_kernel<TM, TN, WM, WN, MODE, BT>;
+  constexpr int lds = gemm_lds_bytes<TM, TN, BT>();
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nt), dim3(256), lds, st, g);
+  HIPCHK(h, hipGetLastError());
+  return SIGP_OK;
+}
+
+// C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
+int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
+  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
+  if (nt <= 0) return SIGP_OK;
+  if (nt >= h->opt_small_tiles) return launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+  g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
+  return launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
+}
+
+// ---- builds -----------------------------------------------------------------------------------------
+void make_kparams(sigp_handle* h, int kernel_id, double ell, double sn) {
+  h->kp.kernel_id = kernel_id;
+  h->kp.c_rbf = -0.5 / (ell * ell);
+  h->kp.inv_ell = 1.0 / ell;
+  h->kp.sn = sn;
+}
+
+// RBF / Matern build of K~ (lower) + ride rows into slot s from device X, y, Xs
+int build_cov(sigp_handle* h, Slot& s, const double* X, const double* y, const double* Xs, long n, long d, long dp,
+              long n_pad, long m, const KParams& kp) {
+  const long ld = n_pad;
+  {
+    ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, (double)n * n / 2 * (3.0 * d + 20), 8.0 * n * d + 4.0 * n * (n + 1));
+    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T));
+    hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, (int)dp, (int)d, (int)n, s.mat, ld, kp);
+    HIPCHK(h, hipGetLastError());
+    dim3 g2((unsigned)(n_pad / 256 + (n_pad % 256 ? 1 : 0)), RIDE);
+    hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, s.s_upd, X, Xs, y, (int)dp, (int)d, (int)n, (int)n_pad, (int)m,
+                       1, s.mat + n_pad * ld, ld, kp, 1);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SIGP_OK;
+}
+
+// ---- blocked Cholesky on slot s (augmented with the ride rows) --------------------------------------
+int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB);   // column blocks
+  const int R = T + 1;               // row blocks including the ride block
+  const int W = std::max(1, h->opt_outer);
+  double* M = s.mat;
+  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
+  static bool diag_attr = false;
+  if (!diag_attr) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    diag_attr = true;
+  }
+  const bool la = h->opt_lookahead != 0;
+  hipStream_t sp = la ? s.s_pan : s.s_upd;   // panel stream
+  hipStream_t su = s.s_upd;
+  if (la) {   // panel stream starts after the build on the update stream
+    HIPCHK(h, hipEventRecord(s.ev_la, su));
+    HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
+  }
+
+  auto panel = [&](int J, int Wc) -> int {
+    for (int i = 0; i < Wc; ++i) {
+      const int c = J + i;
+      {
+        ProfScope ps(h, sp, SIGP_KC_DIAG, 2.0 * NB * NB * NB / 3, 3.0 * NB * NB * 8);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
+                           s.dinv + (long)c * NB * NB, s.info, c * NB);
+        HIPCHK(h, hipGetLastError());
+      }
+      const long o = (long)(c + 1) * NB;
+      const int rows_below = R - (c + 1);   // 128-row blocks below the diagonal block (ride block included)
+      {
+        GemmArgs g{};
+        g.A = M + o * ld + (long)c * NB; g.lda = ld;
+        g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
+        g.C = M + o * ld + (long)c * NB; g.ldc = ld;
+        g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+        ProfScope ps(h, sp, SIGP_KC_TRSM, 2.0 * rows_below * NB * NB * NB, 2.0 * rows_below * NB * NB * 8);
+        int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+        if (rc) return rc;
+      }
+      if (i < Wc - 1) {
+        GemmArgs g{};
+        g.A = M + o * ld + (long)c * NB; g.lda = ld;
+        g.B = g.A; g.ldb = ld;
+        g.C = M + o * ld + o; g.ldc = ld;
+        g.K = NB; g.r0 = 0; g.r1 = rows_below; g.c0 = 0; g.c1 = J + Wc - 1 - c; g.lower = 1;
+        const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
+        ProfScope ps(h, sp, SIGP_KC_UPDATE_INNER, nt * 2.0 * NB * NB * NB, nt * 2.0 * NB * NB * 8);
+        int rc = gemm_sub_auto(h, sp, g);
+        if (rc) return rc;
+      }
+    }
+    return SIGP_OK;
+  };
+  auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
+    const long o = (long)(J + Wc) * NB;
+    GemmArgs g{};
+    g.A = M + o * ld + (long)J * NB; g.lda = ld;
+    g.B = g.A; g.ldb = ld;
+    g.C = M + o * ld + o; g.ldc = ld;
+    g.K = Wc * NB; g.r0 = 0; g.r1 = R - (J + Wc); g.c0 = c0; g.c1 = c1; g.lower = 1;
+    const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
+    if (nt <= 0) return SIGP_OK;
+    ProfScope ps(h, st, SIGP_KC_UPDATE_OUTER, nt * 2.0 * NB * NB * g.K, nt * 2.0 * NB * NB * 8);
+    return gemm_sub_auto(h, st, g);
+  };
+
+  int rc = panel(0, std::min(W, T));
+  if (rc) return rc;
+  for (int J = 0; J < T; J += W) {
+    const int Wc = std::min(W, T - J);
+    const int ncols = T - (J + Wc);            // trailing column blocks
+    if (ncols <= 0) break;
+    const int Wn = std::min(W, ncols);         // width of the next panel
+    if (la) {
+      HIPCHK(h, hipEventRecord(s.ev_pan, sp));            // panel J done
+      HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
+      rc = outer(su, J, Wc, 0, Wn);                       // next panel's columns first
+      if (rc) return rc;
+      HIPCHK(h, hipEventRecord(s.ev_la, su));
+      HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
+      rc = panel(J + Wc, Wn);                             // next panel overlaps the rest of the update
+      if (rc) return rc;
+      rc = outer(su, J, Wc, Wn, ncols);
+      if (rc) return rc;
+    } else {
+      rc = outer(su, J, Wc, 0, ncols);
+      if (rc) return rc;
+      rc = panel(J + Wc, Wn);
+      if (rc) return rc;
+    }
+  }
+  if (la) {   // join: the update stream is the slot's completion stream
+    HIPCHK(h, hipEventRecord(s.ev_pan, sp));
+    HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
+  }
+  return SIGP_OK;
+}
+
+// epilogue reductions on the ride block of slot s + async copy of results / info to pinned host memory
+int epilogue_slot(sigp_handle* h, Slot& s, long n, long n_pad, long m) {
+  const long ld = n_pad;
+  double* Z = s.mat + n_pad * ld;
+  {
+    ProfScope ps(h, s.s_upd, SIGP_KC_EPILOGUE, 4.0 * (m + 1) * n, 8.0 * (m + 2) * n);
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(m + 2)), dim3(256), 0, s.s_upd, Z, ld, Z, s.mat, ld, (int)n, (int)n_pad,
+                       (int)(m + 1), s.res);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
+  return SIGP_OK;
+}
+
+// host-side scalar epilogue (north/June1st.py:267-268, 246, 276-277) from the reductions
+void finish_results(const double* res, int info, long n, long m, double sn_tilde, const double* kss_unit, double* out,
+                    double* mean, double* var) {
+  const double inf = std::numeric_limits<double>::infinity();
+  if (info != 0) {
+    out[0] = inf; out[1] = inf; out[2] = (double)info; out[3] = inf;
+    for (long j = 0; j < m; ++j) { if (mean) mean[j] = std::nan(""); if (var) var[j] = std::nan(""); }
+    return;
+  }
+  const double sf = res[0] / (double)n;                            // sigma_f = y^T A~ / n
+  const double nlml = 0.5 * n + res[256] + 0.5 * n * std::log(sf) + 0.5 * n * std::log(2.0 * M_PI);
+  out[0] = sf; out[1] = nlml; out[2] = 0.0; out[3] = sf * sn_tilde;
+  for (long j = 0; j < m; ++j) {
+    if (mean) mean[j] = res[1 + j];                                // k*^T alpha = v~^T z
+    if (var) var[j] = sf * (kss_unit[j] + sn_tilde - res[128 + 1 + j]);
+  }
+}
+
+int sync_slot(sigp_handle* h, Slot& s) {
+  HIPCHK(h, hipStreamSynchronize(s.s_upd));
+  return SIGP_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+int sigp_version(void) { return 100; }
+
+int sigp_create(sigp_handle** out, int device_id, int dtype) {
+  if (!out) return SIGP_BAD_ARG;
+  *out = nullptr;
+  if (dtype != SIGP_F64) return SIGP_BAD_ARG;   // the f32 + refinement path (config 5) is not built yet
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SIGP_HIP_ERROR;
+  if (hipSetDevice(device_id) != hipSuccess) return SIGP_HIP_ERROR;
+  sigp_handle* h = new sigp_handle();
+  h->device = device_id;
+  h->dtype = dtype;
+  int rc = slot_init(h, h->slots[0]);
+  if (rc) { delete h; return rc; }
+  h->nslots = 1;
+  *out = h;
+  return SIGP_OK;
+}
+
+int sigp_destroy(sigp_handle* h) {
+  if (!h) return SIGP_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  prof_drain(h);
+  for (auto& s : h->slots) slot_free(s);
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs};
+  for (double* p : bufs) if (p) (void)hipFree(p);
+  delete h;
+  return SIGP_OK;
+}
+
+const char* sigp_last_error(const sigp_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
+  if (!h || !name) return SIGP_BAD_ARG;
+  if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 16) return SIGP_BAD_ARG; h->opt_outer = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "lookahead")) { h->opt_lookahead = value ? 1 : 0; return SIGP_OK; }
+  if (!strcmp(name, "small_tile_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_small_tiles = (int)value; return SIGP_OK; }
+  return fail(h, SIGP_BAD_ARG, "unknown option %s", name);
+}
+
+int sigp_set_train(sigp_handle* h, const double* X, int64_t n, int64_t d, int64_t ldx, const double* y) {
+  if (!h || !X || !y || n < 1 || d < 1 || ldx < d) return fail(h, SIGP_BAD_ARG, "set_train: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const long n_pad = round_up(n, NB), dp = round_up(d, 64);
+  int rc;
+  if ((rc = ensure(h, &h->X, &h->cap_X, n_pad * dp))) return rc;
+  if ((rc = ensure(h, &h->y, &h->cap_y, n_pad))) return rc;
+  if ((rc = ensure(h, &h->Xs, &h->cap_Xs, (long)RIDE * dp))) return rc;
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, std::max<long>(n * ldx, n_pad)))) return rc;
+  if ((rc = slot_reserve(h, h->slots[0], n_pad))) return rc;
+  hipStream_t st = h->slots[0].s_upd;
+  HIPCHK(h, hipMemcpyAsync(h->stage, X, (size_t)((n - 1) * ldx + d) * sizeof(double), hipMemcpyHostToDevice, st));
+  {
+    const long tot = n_pad * dp;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldx, (int)n, (int)d,
+                       h->X, (int)n_pad, (int)dp);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipStreamSynchronize(st));   // stage is reused below
+  HIPCHK(h, hipMemsetAsync(h->y, 0, (size_t)n_pad * sizeof(double), st));
+  HIPCHK(h, hipMemcpyAsync(h->y, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->Xs, 0, (size_t)RIDE * dp * sizeof(double), st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->n = n; h->d = d; h->dp = dp; h->n_pad = n_pad; h->m = 0;
+  h->kss_unit.clear();
+  h->built = h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_set_test(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs) {
+  if (!h || h->n == 0 || m < 0 || m > SIGP_MAX_RIDE || (m > 0 && (!Xs || ldxs < h->d))) return fail(h, SIGP_BAD_ARG, "set_test: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->slots[0].s_upd;
+  HIPCHK(h, hipMemsetAsync(h->Xs, 0, (size_t)RIDE * h->dp * sizeof(double), st));
+  if (m > 0) {
+    int rc;
+    if ((rc = ensure(h, &h->stage, &h->cap_stage, m * ldxs))) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->stage, Xs, (size_t)((m - 1) * ldxs + h->d) * sizeof(double), hipMemcpyHostToDevice, st));
+    const long tot = m * h->dp;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldxs, (int)m, (int)h->d,
+                       h->Xs, (int)m, (int)h->dp);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  h->m = m;
+  h->kss_unit.assign((size_t)m, 1.0);   // rbf / matern: k~(x,x) = 1; the reference kernel overwrites this at build
+  h->built = h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde) {
+  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "kernel_build: call set_train first");
+  if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "kernel_build: kernel_id must be RBF or MATERN52 (use kernel_build_from_sigma for the reference kernel)");
+  if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "kernel_build: ell > 0 and sn_tilde >= 0 required");
+  HIPCHK(h, hipSetDevice(h->device));
+  make_kparams(h, kernel_id, ell, sn_tilde);
+  h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
+  h->kss_unit.assign((size_t)h->m, 1.0);
+  int rc = build_cov(h, h->slots[0], h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, h->kp);
+  if (rc) return rc;
+  rc = sync_slot(h, h->slots[0]);
+  if (rc) return rc;
+  h->built = true; h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde) {
+  // K~ = X Sigma~ X^T + sn I  (north/June1st.py:265);  ride rows = [y ; Xs Sigma~ X^T]
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long n = h->n, N = h->d, dp = h->dp, n_pad = h->n_pad, ld = n_pad;
+  int rc;
+  if ((rc = ensure(h, &h->Sig, &h->cap_Sig, dp * dp))) return rc;
+  if ((rc = ensure(h, &h->T, &h->cap_T, n_pad * dp))) return rc;
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, N * ldsigma))) return rc;
+  if (!h->XsA) HIPCHK(h, hipMalloc((void**)&h->XsA, (size_t)RIDE * 4096 * sizeof(double)));
+  if (dp > 4096) return fail(h, SIGP_BAD_ARG, "reference kernel: more than 4096 features not supported");
+  HIPCHK(h, hipMemcpyAsync(h->stage, Sigma, (size_t)((N - 1) * ldsigma + N) * sizeof(double), hipMemcpyHostToDevice, st));
+  {
+    const long tot = dp * dp;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldsigma, (int)N, (int)N,
+                       h->Sig, (int)dp, (int)dp);
+    HIPCHK(h, hipGetLastError());
+  }
+  // T = X Sigma~   (Sigma~ symmetric => X Sigma~^T), 64x64 tiles: n_pad/64 x dp/64
+  {
+    GemmArgs g{};
+    g.A = h->X; g.lda = dp; g.B = h->Sig; g.ldb = dp; g.C = h->T; g.ldc = dp; g.K = (int)dp;
+    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(dp / 64); g.lower = 0;
+    ProfScope ps(h, st, SIGP_KC_KBUILD, 2.0 * n * N * N, 8.0 * (2 * n * N + N * N));
+    if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+  }
+  // K~ lower tiles = T X^T
+  {
+    GemmArgs g{};
+    g.A = h->T; g.lda = dp; g.B = h->X; g.ldb = dp; g.C = s.mat; g.ldc = ld; g.K = (int)dp;
+    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 1;
+    ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * n * N, 4.0 * n * (n + 1) + 16.0 * n * N);
+    if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+    hipLaunchKernelGGL(diag_fix_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, s.mat, ld, (int)n, (int)n_pad, sn_tilde);
+    HIPCHK(h, hipGetLastError());
+  }
+  // ride rows: row 0 <- y, rows 1..m <- Xs T^T  (XsA = Xs shifted down by one row)
+  {
+    HIPCHK(h, hipMemsetAsync(h->XsA, 0, (size_t)RIDE * dp * sizeof(double), st));
+    if (h->m > 0)
+      HIPCHK(h, hipMemcpyAsync(h->XsA + dp, h->Xs, (size_t)h->m * dp * sizeof(double), hipMemcpyDeviceToDevice, st));
+    GemmArgs g{};
+    g.A = h->XsA; g.lda = dp; g.B = h->T; g.ldb = dp; g.C = s.mat + n_pad * ld; g.ldc = ld; g.K = (int)dp;
+    g.r0 = 0; g.r1 = RIDE / 64; g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
+    if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+    KParams kp = h->kp;
+    hipLaunchKernelGGL(ride_build_kernel, dim3((unsigned)((n_pad + 255) / 256), 1), dim3(256), 0, st, h->X, h->Xs, h->y, (int)dp, (int)h->d,
+                       (int)n, (int)n_pad, (int)h->m, 1, s.mat + n_pad * ld, ld, kp, 0);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SIGP_OK;
+}
+
+int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde) {
+  if (!h || h->n == 0 || !Sigma || ldsigma < h->d) return fail(h, SIGP_BAD_ARG, "kernel_build_from_sigma: bad argument");
+  if (!(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "sn_tilde >= 0 required");
+  HIPCHK(h, hipSetDevice(h->device));
+  make_kparams(h, SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde);
+  h->kernel_id = SIGP_KERNEL_NETDIFFUSION; h->ell = 0; h->sn_tilde = sn_tilde;
+  // k~** = xs Sigma~ xs^T on the host (m x N x N flops, tiny): needs the host copies -> recompute from device Xs
+  int rc = build_from_sigma_async(h, Sigma, ldsigma, sn_tilde);
+  if (rc) return rc;
+  if (h->m > 0) {
+    std::vector<double> xs((size_t)h->m * h->dp);
+    HIPCHK(h, hipMemcpyAsync(xs.data(), h->Xs, xs.size() * sizeof(double), hipMemcpyDeviceToHost, h->slots[0].s_upd));
+    HIPCHK(h, hipStreamSynchronize(h->slots[0].s_upd));
+    h->kss_unit.assign((size_t)h->m, 0.0);
+    for (long j = 0; j < h->m; ++j) {
+      double acc = 0.0;
+      for (long a = 0; a < h->d; ++a) {
+        double t = 0.0;
+        for (long b = 0; b < h->d; ++b) t += Sigma[a * ldsigma + b] * xs[j * h->dp + b];
+        acc += xs[j * h->dp + a] * t;
+      }
+      h->kss_unit[j] = acc;
+    }
+  }
+  rc = sync_slot(h, h->slots[0]);
+  if (rc) return rc;
+  h->built = true; h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_potrf(sigp_handle* h, int64_t* info) {
+  if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "potrf: build the kernel matrix first");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc = potrf_slot(h, s, h->n_pad);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
+  rc = sync_slot(h, s);
+  if (rc) return rc;
+  h->built = false;
+  if (info) *info = *s.info_host;
+  if (*s.info_host != 0) { h->factored = false; return fail(h, SIGP_NOT_SPD, "potrf: matrix is not positive definite (pivot %d)", *s.info_host); }
+  h->factored = true; h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_fit(sigp_handle* h, double* sigma_f, double* nlml) {
+  if (!h || !h->factored) return fail(h, SIGP_BAD_ARG, "fit: call potrf first");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc = epilogue_slot(h, s, h->n, h->n_pad, h->m);
+  if (rc) return rc;
+  rc = sync_slot(h, s);
+  if (rc) return rc;
+  double out[4];
+  h->fit_res.assign(s.res_host, s.res_host + 512);
+  finish_results(s.res_host, 0, h->n, 0, h->sn_tilde, nullptr, out, nullptr, nullptr);
+  h->sigma_f = out[0]; h->nlml = out[1]; h->fitted = true;
+  if (sigma_f) *sigma_f = out[0];
+  if (nlml) *nlml = out[1];
+  return SIGP_OK;
+}
+
+int sigp_predict_ride(sigp_handle* h, double* mean, double* var) {
+  if (!h || !h->fitted) return fail(h, SIGP_BAD_ARG, "predict_ride: call fit first");
+  double out[4];
+  finish_results(h->fit_res.data(), 0, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+  return SIGP_OK;
+}
+
+int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma,
+                     double* out, double* mean, double* var) {
+  if (!h || h->n == 0 || !out) return fail(h, SIGP_BAD_ARG, "fit_predict: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc;
+  if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
+    if (!Sigma) return fail(h, SIGP_BAD_ARG, "fit_predict: Sigma required for the reference kernel");
+    rc = sigp_kernel_build_from_sigma(h, Sigma, ldsigma, sn_tilde);
+    if (rc) return rc;
+  } else {
+    if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "bad kernel_id");
+    if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "ell > 0 and sn_tilde >= 0 required");
+    make_kparams(h, kernel_id, ell, sn_tilde);
+    h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
+    h->kss_unit.assign((size_t)h->m, 1.0);
+    rc = build_cov(h, s, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, h->kp);
+    if (rc) return rc;
+  }
+  if ((rc = potrf_slot(h, s, h->n_pad))) return rc;
+  if ((rc = epilogue_slot(h, s, h->n, h->n_pad, h->m))) return rc;
+  if ((rc = sync_slot(h, s))) return rc;
+  const int info = *s.info_host;
+  h->fit_res.assign(s.res_host, s.res_host + 512);
+  finish_results(s.res_host, info, h->n, h->m, sn_tilde, h->kss_unit.data(), out, mean, var);
+  h->built = false;
+  h->factored = h->fitted = (info == 0);
+  h->sigma_f = out[0]; h->nlml = out[1];
+  if (info != 0) return fail(h, SIGP_NOT_SPD, "fit_predict: matrix is not positive definite (pivot %d)", info);
+  return SIGP_OK;
+}
+
+// ---- forward / backward block solves on a scratch ride block (predict for new points, alpha) --------
+static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
+  // Z[128][n_pad] <- Z L~^-T  : per block column kb: Z[:,kb] = Z[:,kb] inv(L_kk)^T ; Z[:,kb+1:] -= Z[:,kb] L[kb+1:,kb]^T
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  hipStream_t st = s.s_upd;
+  for (int kb = 0; kb < T; ++kb) {
+    GemmArgs g{};
+    g.A = Z + (long)kb * NB; g.lda = ld; g.B = s.dinv + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
+    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, st, g);
+    if (rc) return rc;
+    if (kb + 1 < T) {
+      GemmArgs u{};
+      u.A = Z + (long)kb * NB; u.lda = ld;
+      u.B = s.mat + (long)(kb + 1) * NB * ld + (long)kb * NB; u.ldb = ld;
+      u.C = Z + (long)(kb + 1) * NB; u.ldc = ld;
+      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = (T - kb - 1) * 2; u.lower = 0;
+      rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, u);
+      if (rc) return rc;
+    }
+  }
+  return SIGP_OK;
+}
+
+static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
+  // Z <- Z L~^-1 : from the last block column: Z[:,kb] = Z[:,kb] inv(L_kk) ; Z[:, :kb] -= Z[:,kb] L[kb, :kb]
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  hipStream_t st = s.s_upd;
+  for (int kb = T - 1; kb >= 0; --kb) {
+    GemmArgs g{};
+    g.A = Z + (long)kb * NB; g.lda = ld; g.B = s.dinv + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
+    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, true>(h, st, g);
+    if (rc) return rc;
+    if (kb > 0) {
+      GemmArgs u{};
+      u.A = Z + (long)kb * NB; u.lda = ld;
+      u.B = s.mat + (long)kb * NB * ld; u.ldb = ld;       // K x N image: rows kb*128.., all columns < kb*128
+      u.C = Z; u.ldc = ld;
+      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = kb * 2; u.lower = 0;
+      rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, true>(h, st, u);
+      if (rc) return rc;
+    }
+  }
+  return SIGP_OK;
+}
+
+int sigp_get_alpha(sigp_handle* h, double* alpha_tilde) {
+  if (!h || !h->factored || !alpha_tilde) return fail(h, SIGP_BAD_ARG, "get_alpha: call potrf first");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  const long n_pad = h->n_pad, ld = n_pad;
+  int rc;
+  if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, (long)RIDE * n_pad))) return rc;
+  HIPCHK(h, hipMemsetAsync(h->scratchZ, 0, (size_t)RIDE * n_pad * sizeof(double), s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(h->scratchZ, s.mat + n_pad * ld, (size_t)n_pad * sizeof(double), hipMemcpyDeviceToDevice, s.s_upd));   // row 0 = z
+  if ((rc = solve_rows_backward(h, s, h->scratchZ, n_pad))) return rc;
+  HIPCHK(h, hipMemcpyAsync(alpha_tilde, h->scratchZ, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost, s.s_upd));
+  return sync_slot(h, s);
+}
+
+int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, double* mean, double* var) {
+  if (!h || !h->fitted || !Xs || m < 1 || ldxs < h->d || !mean || !var) return fail(h, SIGP_BAD_ARG, "predict: bad argument or fit() not called");
+  if (h->kernel_id == SIGP_KERNEL_NETDIFFUSION && !h->T) return fail(h, SIGP_BAD_ARG, "predict: no Sigma state");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  const long n = h->n, n_pad = h->n_pad, ld = n_pad, dp = h->dp;
+  int rc;
+  if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, (long)RIDE * n_pad))) return rc;
+  const long xs_off = RIDE * std::max<long>(ldxs, dp);   // stage = [raw chunk | padded chunk [128][dp]]
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, xs_off + RIDE * dp))) return rc;
+  double* xs_dev = h->stage + xs_off;
+  hipStream_t st = s.s_upd;
+  const double* z = s.mat + n_pad * ld;   // solved row 0 of the ride block: z = L~^-1 y
+  std::vector<double> xs_host((size_t)RIDE * dp);
+  for (long c0 = 0; c0 < m; c0 += RIDE) {
+    const long mc = std::min<long>(RIDE, m - c0);
+    HIPCHK(h, hipMemcpyAsync(h->stage, Xs + c0 * ldxs, (size_t)((mc - 1) * ldxs + h->d) * sizeof(double), hipMemcpyHostToDevice, st));
+    {
+      const long tot = RIDE * dp;
+      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldxs, (int)mc, (int)h->d,
+                         xs_dev, RIDE, (int)dp);
+      HIPCHK(h, hipGetLastError());
+    }
+    std::vector<double> kss((size_t)mc, 1.0);
+    if (h->kernel_id == SIGP_KERNEL_NETDIFFUSION) {
+      GemmArgs g{};
+      g.A = xs_dev; g.lda = dp; g.B = h->T; g.ldb = dp; g.C = h->scratchZ; g.ldc = ld; g.K = (int)dp;
+      g.r0 = 0; g.r1 = RIDE / 64; g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
+      if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+      // k~** = xs Sigma~ xs^T : T_s = xs Sigma~ via the same GEMM on a 128 x dp block, then row dots on the host
+      GemmArgs g2{};
+      double* ts = h->XsA;   // reuse [128][dp] workspace
+      g2.A = xs_dev; g2.lda = dp; g2.B = h->Sig; g2.ldb = dp; g2.C = ts; g2.ldc = dp; g2.K = (int)dp;
+      g2.r0 = 0; g2.r1 = RIDE / 64; g2.c0 = 0; g2.c1 = (int)(dp / 64); g2.lower = 0;
+      if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g2))) return rc;
+      std::vector<double> ts_host((size_t)RIDE * dp);
+      HIPCHK(h, hipMemcpyAsync(ts_host.data(), ts, ts_host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipMemcpyAsync(xs_host.data(), xs_dev, xs_host.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      for (long j = 0; j < mc; ++j) {
+        double acc = 0.0;
+        for (long a = 0; a < h->d; ++a) acc += ts_host[j * dp + a] * xs_host[j * dp + a];
+        kss[j] = acc;
+      }
+    } else {
+      dim3 g2((unsigned)((n_pad + 255) / 256), RIDE);
+      hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, st, h->X, xs_dev, (const double*)nullptr, (int)dp, (int)h->d, (int)n,
+                         (int)n_pad, (int)mc, 0, h->scratchZ, ld, h->kp, 1);
+      HIPCHK(h, hipGetLastError());
+    }
+    if ((rc = solve_rows_forward(h, s, h->scratchZ, n_pad))) return rc;
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(mc + 1)), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
+                       (int)n_pad, (int)mc, s.res);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (long j = 0; j < mc; ++j) {
+      mean[c0 + j] = s.res_host[j];
+      var[c0 + j] = h->sigma_f * (kss[j] + h->sn_tilde - s.res_host[128 + j]);
+    }
+  }
+  return SIGP_OK;
+}
+
+int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo) {
+  if (!h || !out || ldo < h->n || h->n == 0) return fail(h, SIGP_BAD_ARG, "get_matrix: bad argument");
+  if (which == SIGP_MAT_K && !h->built) return fail(h, SIGP_BAD_ARG, "get_matrix: K~ is not resident (build it, and fetch before potrf)");
+  if (which == SIGP_MAT_L && !h->factored) return fail(h, SIGP_BAD_ARG, "get_matrix: L~ is not resident");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  HIPCHK(h, hipMemcpy2D(out, (size_t)ldo * sizeof(double), s.mat, (size_t)h->n_pad * sizeof(double), (size_t)h->n * sizeof(double),
+                        (size_t)h->n, hipMemcpyDeviceToHost));
+  for (long i = 0; i < h->n; ++i)
+    for (long j = i + 1; j < h->n; ++j) out[i * ldo + j] = 0.0;
+  return SIGP_OK;
+}
+
+// ---- batch ---------------------------------------------------------------------------------------------
+int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t strideX, const double* y, int64_t stridey,
+                      const double* Xs, int64_t strideXs, int64_t n, int64_t d, int64_t m) {
+  if (!h || batch < 1 || !X || !y || n < 1 || d < 1 || m < 0 || m > SIGP_MAX_RIDE || (m > 0 && !Xs)) return fail(h, SIGP_BAD_ARG, "batch_upload: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  const long n_pad = round_up(n, NB), dp = round_up(d, 64);
+  for (double** p : {&h->bX, &h->by, &h->bXs}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&h->bX, (size_t)batch * n_pad * dp * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->by, (size_t)batch * n_pad * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->bXs, (size_t)batch * RIDE * dp * sizeof(double)));
+  HIPCHK(h, hipMemset(h->by, 0, (size_t)batch * n_pad * sizeof(double)));
+  HIPCHK(h, hipMemset(h->bXs, 0, (size_t)batch * RIDE * dp * sizeof(double)));
+  HIPCHK(h, hipDeviceSynchronize());   // the slot streams are non-blocking: order them after the null-stream memsets
+  int rc;
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, std::max<long>(n * d, RIDE * d)))) return rc;
+  hipStream_t st = h->slots[0].s_upd;
+  for (long b = 0; b < batch; ++b) {
+    const double* Xb = X + b * strideX;
+    HIPCHK(h, hipMemcpyAsync(h->stage, Xb, (size_t)n * d * sizeof(double), hipMemcpyHostToDevice, st));
+    long tot = n_pad * dp;
+    hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)d, (int)n, (int)d,
+                       h->bX + b * n_pad * dp, (int)n_pad, (int)dp);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    HIPCHK(h, hipMemcpyAsync(h->by + b * n_pad, y + b * stridey, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+    if (m > 0) {
+      HIPCHK(h, hipMemcpyAsync(h->stage, Xs + b * strideXs, (size_t)m * d * sizeof(double), hipMemcpyHostToDevice, st));
+      tot = m * dp;
+      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)d, (int)m, (int)d,
+                         h->bXs + b * RIDE * dp, (int)m, (int)dp);
+      HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(st));
+  }
+  h->b_count = batch; h->b_n = n; h->b_d = d; h->b_dp = dp; h->b_m = m; h->b_npad = n_pad;
+  return SIGP_OK;
+}
+
+int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* ell, const double* sn_tilde,
+                   int concurrency, double* out, double* mean, double* var) {
+  if (!h || h->b_count == 0 || first < 0 || count < 1 || !ell || !sn_tilde || !out) return fail(h, SIGP_BAD_ARG, "batch_run: bad argument");
+  if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "batch_run: RBF / MATERN52 only");
+  if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..8");
+  HIPCHK(h, hipSetDevice(h->device));
+  const long n = h->b_n, d = h->b_d, dp = h->b_dp, m = h->b_m, n_pad = h->b_npad;
+  int rc;
+  for (int k = 0; k < concurrency; ++k)
+    if ((rc = slot_reserve(h, h->slots[k], n_pad))) return rc;
+  h->nslots = std::max(h->nslots, concurrency);
+  std::vector<double> kss((size_t)std::max<long>(m, 1), 1.0);
+  std::vector<long> inflight((size_t)concurrency, -1);
+  std::vector<double> snv((size_t)concurrency, 0.0);
+  auto retire = [&](int k) -> int {
+    Slot& s = h->slots[k];
+    HIPCHK(h, hipStreamSynchronize(s.s_upd));
+    const long i = inflight[k];
+    finish_results(s.res_host, *s.info_host, n, m, snv[k], kss.data(), out + 4 * i, mean ? mean + i * m : nullptr,
+                   var ? var + i * m : nullptr);
+    inflight[k] = -1;
+    return SIGP_OK;
+  };
+  for (long i = 0; i < count; ++i) {
+    const int k = (int)(i % concurrency);
+    if (inflight[k] >= 0 && (rc = retire(k))) return rc;
+    Slot& s = h->slots[k];
+    const long b = (first + i) % h->b_count;
+    KParams kp;
+    kp.kernel_id = kernel_id; kp.c_rbf = -0.5 / (ell[i] * ell[i]); kp.inv_ell = 1.0 / ell[i]; kp.sn = sn_tilde[i];
+    if (!(ell[i] > 0) || !(sn_tilde[i] >= 0)) return fail(h, SIGP_BAD_ARG, "batch_run: ell > 0 and sn_tilde >= 0 required");
+    if ((rc = build_cov(h, s, h->bX + b * n_pad * dp, h->by + b * n_pad, h->bXs + b * RIDE * dp, n, d, dp, n_pad, m, kp))) return rc;
+    if ((rc = potrf_slot(h, s, n_pad))) return rc;
+    if ((rc = epilogue_slot(h, s, n, n_pad, m))) return rc;
+    inflight[k] = i; snv[k] = sn_tilde[i];
+  }
+  for (int k = 0; k < concurrency; ++k)
+    if (inflight[k] >= 0 && (rc = retire(k))) return rc;
+  // slot 0 no longer holds the single-fit state
+  h->built = h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X, int64_t strideX, const double* y, int64_t stridey,
+                   const double* Xs, int64_t strideXs, int64_t n, int64_t d, int64_t m, const double* ell, const double* sn_tilde,
+                   int concurrency, double* out, double* mean, double* var) {
+  // distinct data sets = distinct (X, y, Xs) triples; with all strides 0 the batch is one data set x many grid points
+  const int64_t nsets = (strideX == 0 && stridey == 0 && strideXs == 0) ? 1 : batch;
+  int rc = sigp_batch_upload(h, nsets, X, strideX, y, stridey, Xs, strideXs, n, d, m);
+  if (rc) return rc;
+  return sigp_batch_run(h, 0, batch, kernel_id, ell, sn_tilde, concurrency, out, mean, var);
+}
+
+int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma, const double* MSigma, int64_t ldsigma,
+                   int grad_mode, double* nlml, double grad[2]) {
+  if (!h || !theta || !nlml) return fail(h, SIGP_BAD_ARG, "nlml_grad: bad argument");
+  const double inf = std::numeric_limits<double>::infinity();
+  if (grad_mode != 0) return fail(h, SIGP_BAD_ARG, "nlml_grad: gradient modes are not built yet (grad_mode must be 0)");
+  (void)MSigma;
+  double out[4];
+  int rc = sigp_fit_predict(h, kernel_id, std::exp(theta[0]), std::exp(theta[1]), Sigma, ldsigma, out, nullptr, nullptr);
+  if (rc == SIGP_NOT_SPD) { *nlml = inf; if (grad) grad[0] = grad[1] = inf; return rc; }
+  if (rc) return rc;
+  *nlml = out[1];
+  return SIGP_OK;
+}
+
+int sigp_profile(sigp_handle* h, int enable) {
+  if (!h) return SIGP_BAD_ARG;
+  if (!enable) prof_drain(h);
+  h->prof = enable != 0;
+  return SIGP_OK;
+}
+
+int sigp_profile_reset(sigp_handle* h) {
+  if (!h) return SIGP_BAD_ARG;
+  prof_drain(h);
+  for (int k = 0; k < SIGP_KC_COUNT; ++k) { h->p_ms[k] = 0; h->p_n[k] = 0; h->p_flops[k] = 0; h->p_bytes[k] = 0; }
+  return SIGP_OK;
+}
+
+int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* launches, double* flops, double* bytes) {
+  if (!h || kclass < 0 || kclass >= SIGP_KC_COUNT) return SIGP_BAD_ARG;
+  prof_drain(h);
+  if (total_ms) *total_ms = h->p_ms[kclass];
+  if (launches) *launches = h->p_n[kclass];
+  if (flops) *flops = h->p_flops[kclass];
+  if (bytes) *bytes = h->p_bytes[kclass];
+  return SIGP_OK;
+}
+
+}  // extern "C"

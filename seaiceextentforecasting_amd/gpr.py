@@ -1,0 +1,287 @@
+"""``GPR``: the fit / predict / nlml call sites that replace the reference's inline GP block
+(north/June1st.py:231-277 and its 13 byte-identical siblings).
+
+A script's block becomes::
+
+    gp = GPR(kernel="netdiffusion")
+    gp.fit(X, y, l_init[k], sigma_init[k], M=M, Xs=Xs)      # :264-271
+    fmean, fvar = gp.predict(Xs)                            # :272-277  (fvar includes sigma_n)
+
+All numerics run in HIP kernels behind libsigp.so (include/sigp.h).  There is no CPU fallback: without
+the library or a GPU the constructor raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .features import laplacian_M, sigma_tilde
+
+
+class LinAlgError(np.linalg.LinAlgError):
+    """Raised where the reference's live block raises ``np.linalg.LinAlgError`` (non-SPD K~ at
+    north/June1st.py:265); carries the LAPACK-style pivot index in ``.info``."""
+
+    def __init__(self, msg, info=0):
+        super().__init__(msg)
+        self.info = info
+
+
+class GPR:
+    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None):
+        if kernel not in L.KERNEL_IDS:
+            raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
+        if dtype != "f64":
+            raise NotImplementedError("dtype %r: only the fp64 engine is built (config 5's fp32 + refinement is not)" % dtype)
+        self.kernel = kernel
+        self._kid = L.KERNEL_IDS[kernel]
+        self._lib = L.load()
+        h = C.c_void_p()
+        rc = self._lib.sigp_create(C.byref(h), int(device), 0)
+        if rc != L.OK:
+            raise L.SigpError("sigp_create(device=%d) failed (rc=%d): no usable MI355X / HIP runtime; there is no CPU fallback"
+                              % (device, rc))
+        self._h = h
+        self.device = device
+        self._has_data = False
+        self._fitted = False
+        self._ride = None
+        if outer_blocks is not None:
+            self.set_option("outer_blocks", outer_blocks)
+        if lookahead is not None:
+            self.set_option("lookahead", int(bool(lookahead)))
+
+    # ---- plumbing ------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc == L.OK:
+            return
+        msg = self._lib.sigp_last_error(self._h)
+        msg = msg.decode() if msg else ""
+        if rc == L.NOT_SPD:
+            raise LinAlgError("%s: %s" % (what, msg or "Matrix is not positive definite"))
+        if rc == L.BAD_ARG:
+            raise ValueError("%s: %s" % (what, msg))
+        raise L.SigpError("%s: %s" % (what, msg))
+
+    def set_option(self, name, value):
+        self._check(self._lib.sigp_set_option(self._h, name.encode(), int(value)), "set_option")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.sigp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- data ----------------------------------------------------------------------------------
+    def set_data(self, X, y, M=None, Xs=None):
+        """Stage the enclosing-scope variables of the reference block (X, y, M, Xs) in HBM."""
+        X = L.f64(X, 2)
+        y = L.f64(np.asarray(y).reshape(-1), 1)
+        if y.shape[0] != X.shape[0]:
+            raise ValueError("X has %d rows but y has %d" % (X.shape[0], y.shape[0]))
+        self._check(self._lib.sigp_set_train(self._h, L.ptr(X), X.shape[0], X.shape[1], X.shape[1], L.ptr(y)), "set_train")
+        self.n, self.d = X.shape
+        self._X, self._y = X, y
+        self._M = None
+        if self.kernel == "netdiffusion":
+            self._M = laplacian_M(X) if M is None else L.f64(M, 2)
+            if self._M.shape != (self.d, self.d):
+                raise ValueError("M must be %dx%d" % (self.d, self.d))
+        self._set_ride(Xs)
+        self._has_data = True
+        self._fitted = False
+
+    def _set_ride(self, Xs):
+        if Xs is None:
+            self._ride = None
+            self._check(self._lib.sigp_set_test(self._h, None, 0, 0), "set_test")
+            return
+        Xs = L.f64(np.atleast_2d(Xs), 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError("Xs must have %d columns" % self.d)
+        if Xs.shape[0] > L.MAX_RIDE:
+            self._ride = None      # too many to ride along: predict() takes the general path
+            self._check(self._lib.sigp_set_test(self._h, None, 0, 0), "set_test")
+            return
+        self._check(self._lib.sigp_set_test(self._h, L.ptr(Xs), Xs.shape[0], Xs.shape[1]), "set_test")
+        self._ride = Xs
+
+    # ---- fit (north/June1st.py:264-271) --------------------------------------------------------
+    def fit(self, X, y, ell, sn_tilde, M=None, Xs=None):
+        """Kernel build -> Cholesky -> A~ -> profiled sigma_f.  ``Xs`` (optional, <= 127 rows) rides along
+        the factorisation so the following ``predict(Xs)`` costs nothing extra.  Raises LinAlgError
+        if K~ is not positive definite, as the reference's live block does."""
+        self.set_data(X, y, M=M, Xs=Xs)
+        return self.refit(ell, sn_tilde)
+
+    def refit(self, ell, sn_tilde):
+        """Fit again on the staged data with new hyper-parameters (grid search / optimiser loop)."""
+        if not self._has_data:
+            raise RuntimeError("refit: no data staged; call fit() or set_data() first")
+        out = np.zeros(4)
+        m = 0 if self._ride is None else self._ride.shape[0]
+        mean = np.zeros(max(m, 1))
+        var = np.zeros(max(m, 1))
+        Sig = None
+        if self.kernel == "netdiffusion":
+            Sig = L.f64(sigma_tilde(self._M, float(ell)), 2)
+            self._Sigma_tilde = Sig
+        self._fitted = False
+        rc = self._lib.sigp_fit_predict(self._h, self._kid, float(ell), float(sn_tilde), L.ptr(Sig),
+                                        0 if Sig is None else Sig.shape[1], L.ptr(out), L.ptr(mean), L.ptr(var))
+        self.info_ = int(out[2]) if rc in (L.OK, L.NOT_SPD) else -1
+        if rc == L.NOT_SPD:
+            raise LinAlgError("Matrix is not positive definite (pivot %d)" % self.info_, self.info_)
+        self._check(rc, "fit")
+        self.ell_, self.sn_tilde_ = float(ell), float(sn_tilde)
+        self.sigma_f_, self.nlml_, self.sigma_n_ = float(out[0]), float(out[1]), float(out[3])
+        self._ride_mean, self._ride_var = mean[:m].copy(), var[:m].copy()
+        self._fitted = True
+        return self
+
+    # ---- predict (north/June1st.py:272-277) ----------------------------------------------------
+    def predict(self, Xs):
+        """(fmean [m], fvar [m]); fvar is the variance of y*, i.e. includes sigma_n (:273, :277)."""
+        if not self._fitted:
+            raise RuntimeError("predict: call fit() first")
+        Xs = L.f64(np.atleast_2d(Xs), 2)
+        if Xs.shape[1] != self.d:
+            raise ValueError("Xs must have %d columns" % self.d)
+        if self._ride is not None and Xs.shape == self._ride.shape and np.array_equal(Xs, self._ride):
+            return self._ride_mean.copy(), self._ride_var.copy()
+        m = Xs.shape[0]
+        mean, var = np.zeros(m), np.zeros(m)
+        self._check(self._lib.sigp_predict(self._h, L.ptr(Xs), m, Xs.shape[1], L.ptr(mean), L.ptr(var)), "predict")
+        return mean, var
+
+    # ---- MLII (north/June1st.py:235-257) -------------------------------------------------------
+    def nlml(self, theta, grad=None):
+        """``MLII(hyperparameters)``: theta = (log l, log sn~) -> (nlML, grad[2]).  Non-SPD K~ gives
+        ``(inf, [inf, inf])`` like the reference's except branch (:254-256).  ``grad`` None returns the
+        value only (gradient entry None); 'ref' / 'exact' gradients are not built on the device yet."""
+        if not self._has_data:
+            raise RuntimeError("nlml: no data staged; call fit() or set_data() first")
+        if grad not in (None,):
+            raise NotImplementedError("nlml gradient mode %r is not built yet (K13/K14)" % (grad,))
+        theta = np.asarray(theta, dtype=np.float64).reshape(2)
+        try:
+            with np.errstate(over="raise"):
+                ell, snt = float(np.exp(theta[0])), float(np.exp(theta[1]))
+            self.refit(ell, snt)
+        except (LinAlgError, ValueError, OverflowError, FloatingPointError):
+            return np.inf, np.asarray([np.inf, np.inf])
+        return np.float64(self.nlml_), None
+
+    # ---- state accessors -----------------------------------------------------------------------
+    @property
+    def alpha_(self):
+        """alpha = K^-1 y = A~/sigma_f (north/June1st.py:271), shape (n, 1)."""
+        a = np.zeros(self.n)
+        self._check(self._lib.sigp_get_alpha(self._h, L.ptr(a)), "get_alpha")
+        return (a / self.sigma_f_).reshape(-1, 1)
+
+    @property
+    def L_tilde_(self):
+        out = np.zeros((self.n, self.n))
+        self._check(self._lib.sigp_get_matrix(self._h, 1, L.ptr(out), self.n), "get_matrix")
+        return out
+
+    @property
+    def L_(self):
+        """L = chol(K) = sqrt(sigma_f) L~ (north/June1st.py:270)."""
+        return np.sqrt(self.sigma_f_) * self.L_tilde_
+
+    def kernel_matrix(self, ell, sn_tilde):
+        """K~ (lower triangle) as built on the device -- test/diagnostic accessor."""
+        if self.kernel == "netdiffusion":
+            Sig = L.f64(sigma_tilde(self._M, float(ell)), 2)
+            self._check(self._lib.sigp_kernel_build_from_sigma(self._h, L.ptr(Sig), Sig.shape[1], float(sn_tilde)), "kernel_build")
+        else:
+            self._check(self._lib.sigp_kernel_build(self._h, self._kid, float(ell), float(sn_tilde)), "kernel_build")
+        out = np.zeros((self.n, self.n))
+        self._check(self._lib.sigp_get_matrix(self._h, 0, L.ptr(out), self.n), "get_matrix")
+        self._fitted = False
+        return out
+
+    # ---- batches (retro loop :176-248, grid :210-211) ------------------------------------------
+    def fit_batch(self, X, y, Xs, ell, sn_tilde, concurrency=2):
+        """Independent fits sharing (n, d, m).  X [B,n,d] (or [n,d] shared), y [B,n] (or [n]), Xs [B,m,d]
+        (or [m,d] / None), ell [F], sn_tilde [F]; F fits, fit i uses data set i % B.  RBF / Matern only.
+        Returns dict(sigma_f, nlml, info, sigma_n, mean [F,m], var [F,m])."""
+        if self.kernel == "netdiffusion":
+            raise NotImplementedError("fit_batch: the reference kernel batches on the host loop (retro.retro_forecast)")
+        X = L.f64(X)
+        shared = X.ndim == 2
+        Xb = X[None] if shared else X
+        B, n, d = Xb.shape
+        yb = L.f64(np.asarray(y).reshape(B, n))
+        m = 0
+        Xsb = None
+        if Xs is not None:
+            Xsb = L.f64(Xs)
+            Xsb = Xsb[None] if Xsb.ndim == 2 else Xsb
+            if Xsb.shape[0] != B or Xsb.shape[2] != d:
+                raise ValueError("Xs must be [B,m,d]")
+            m = Xsb.shape[1]
+        ell = L.f64(np.atleast_1d(ell), 1)
+        sn = L.f64(np.atleast_1d(sn_tilde), 1)
+        F = len(ell)
+        if len(sn) != F:
+            raise ValueError("ell and sn_tilde must have the same length")
+        self._check(self._lib.sigp_batch_upload(self._h, B, L.ptr(Xb), n * d, L.ptr(yb), n, L.ptr(Xsb), m * d, n, d, m), "batch_upload")
+        self._batch_m = m
+        return self.run_batch(0, F, ell, sn, concurrency)
+
+    def run_batch(self, first, count, ell, sn_tilde, concurrency=2):
+        """Run ``count`` fits on the data sets already resident in HBM (after fit_batch / upload)."""
+        ell = L.f64(np.atleast_1d(ell), 1)
+        sn = L.f64(np.atleast_1d(sn_tilde), 1)
+        out = np.zeros((count, 4))
+        if len(ell) != count or len(sn) != count:
+            raise ValueError("ell and sn_tilde must have `count` entries")
+        mdim = getattr(self, "_batch_m", 0)
+        mean = np.zeros((count, max(mdim, 1)))
+        var = np.zeros((count, max(mdim, 1)))
+        rc = self._lib.sigp_batch_run(self._h, int(first), int(count), self._kid, L.ptr(ell), L.ptr(sn), int(concurrency),
+                                      L.ptr(out), L.ptr(mean) if mdim else None, L.ptr(var) if mdim else None)
+        self._check(rc, "batch_run")
+        self._fitted = False
+        return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
+                    mean=mean[:, :mdim], var=var[:, :mdim])
+
+    def nlml_grid(self, X, y, ells, sns, concurrency=2):
+        """nlML on the (l, sn~) grid for one data set -- the offline 20x20 search implied by
+        north/June1st.py:210-211.  Returns [len(ells), len(sns)], +inf where K~ is not SPD."""
+        ells = np.asarray(ells, dtype=np.float64).reshape(-1)
+        sns = np.asarray(sns, dtype=np.float64).reshape(-1)
+        E, S = np.meshgrid(ells, sns, indexing="ij")
+        r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency)
+        return r["nlml"].reshape(len(ells), len(sns))
+
+    # ---- measurement ---------------------------------------------------------------------------
+    def profile(self, enable=True):
+        self._check(self._lib.sigp_profile(self._h, int(bool(enable))), "profile")
+
+    def profile_reset(self):
+        self._check(self._lib.sigp_profile_reset(self._h), "profile_reset")
+
+    def profile_get(self):
+        """{kernel class: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
+        out = {}
+        for name, k in L.KCLASS.items():
+            ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+            nl = C.c_int64()
+            self._check(self._lib.sigp_profile_get(self._h, k, C.byref(ms), C.byref(nl), C.byref(fl), C.byref(by)), "profile_get")
+            out[name] = dict(ms=ms.value, launches=nl.value, flops=fl.value, bytes=by.value)
+        return out
