@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""bench.py -- GP fits/sec (n x n fp64, kernel build + Cholesky + predict) on N MI355X.
+
+A step = one GP fit of the BASELINE.json configs[2] workload (n=8192, d=8, fp64 RBF, one retrospective
+"year" x one hyper-parameter grid point): kernel-matrix build -> blocked Cholesky (with y and the test
+point riding along) -> sigma_f, nlML, predictive mean/variance at m=1.  Inputs (the years' X, y, Xs) are
+resident in HBM before the timed region.  N>1: ranks hold different years (independent fits, no data-path
+collective) -> weak scaling; value = total fits / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 8] [--concurrency C]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (= fp64 vector peak), SURVEY.md 8(d)
+
+
+def grid_point(i, d):
+    """Step i's hyper-parameters: the 4x4 'smoke' grid of SURVEY 8(d) around l = sqrt(d), sn~ = 1e-2."""
+    ells = np.sqrt(d) * np.logspace(-0.5, 0.5, 4)
+    sns = np.logspace(-3, -1, 4)
+    return ells[i % 4], sns[(i // 4) % 4]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=24)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--n", type=int, default=8192)
+    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--years", type=int, default=8, help="distinct synthetic data sets resident per rank")
+    ap.add_argument("--concurrency", type=int, default=2)
+    ap.add_argument("--outer", type=int, default=None)
+    ap.add_argument("--reserve-cus", type=int, default=None)
+    ap.add_argument("--host-timing", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+
+    from oracle import gp_oracle as O                       # synthetic generator + cpu_baseline leg only
+    from seaiceextentforecasting_amd import GPR
+
+    n, d, m = args.n, args.d, 1
+    years = max(1, args.years)
+    Xb = np.zeros((years, n, d)); yb = np.zeros((years, n)); Xsb = np.zeros((years, m, d))
+    for b in range(years):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 20240002 + 1000 * rank + b, m=m)
+
+    gp = GPR(kernel="rbf", device=local, outer_blocks=args.outer, reserve_cus=args.reserve_cus)
+    for o in args.opt:
+        k, v = o.split("=")
+        gp.set_option(k, int(v))
+    if args.host_timing:
+        gp.set_option("host_timing", 1)
+    K, W = args.steps, args.warmup
+    ell = np.array([grid_point(i, d)[0] for i in range(W + K)])
+    sn = np.array([grid_point(i, d)[1] for i in range(W + K)])
+    # upload (outside the timed region) + warm-up
+    r = gp.fit_batch(Xb, yb, Xsb, ell[:max(W, 1)], sn[:max(W, 1)], concurrency=args.concurrency)
+    assert np.all(r["info"] == 0)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if not args.no_profile:
+        gp.profile(True)
+    gp.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    r = gp.run_batch(W, K, ell[W:], sn[W:], concurrency=args.concurrency)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    prof = gp.profile_get()
+    gp.profile(False)
+    elapsed = t1 - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert np.all(r["info"] == 0) and np.all(np.isfinite(r["mean"]))
+
+    fits = K * world
+    value = fits / elapsed
+    flops_fit = n ** 3 / 3 + n ** 2 / 2 + n / 6 + n * n * d + n * n / 2 + 2 * n * n + m * (2 * n * d + n * n + 4 * n)
+    out = {
+        "metric": "GP fits/sec (n x n fp64, kernel+Cholesky+predict)", "value": value, "unit": "fits/s",
+        "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: n=%d d=%d fp64 RBF GPR, batch of retrospective years x hyper-parameter grid, "
+                               "one fit per step (kernel build + blocked Cholesky + sigma_f/nlML + predict m=1)" % (n, d),
+                   "years_resident": years, "concurrency": args.concurrency, "parallelism": "years sharded over %d GPU(s), no collective" % world},
+        "whole_fit_tflops": value * flops_fit / 1e12 / world,
+        "whole_fit_frac_of_fp64_mfma_peak": value * flops_fit / 1e12 / world / PEAK_F64_MFMA_TFLOPS,
+    }
+    if rank == 0:
+        dom = prof["update_outer"]
+        if dom["launches"] and dom["ms"] > 0:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_kernel (outer trailing update, C -= A B^T)",
+                               "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS,
+                               "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
+                               "flops_per_launch": dom["flops"] / dom["launches"]}
+        else:
+            out["roofline"] = None
+        kb = prof["kbuild"]
+        out["kernels"] = {k: {"ms_per_fit": v["ms"] / K, "launches_per_fit": v["launches"] / K,
+                              "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None,
+                              "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None} for k, v in prof.items()}
+        del kb
+    gp.close()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # reference-idiom CPU path (oracle, call-for-call north/June1st.py:264-277) on the host cores, one fit
+        ncpu = os.cpu_count()
+        nb = n if n <= 8192 else 8192
+        Xc, yc, Xsc = O.synthetic_problem(nb, d, 20240002, m=1)
+        t0 = time.perf_counter()
+        ref = O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=True)
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
+                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True (NumPy %s / OpenBLAS, %d threads)" % (nb, d, np.__version__, ncpu),
+                               "seconds": tc}
+        if nb == n:   # parity of the timed configuration against the CPU path on the same inputs
+            with GPR(kernel="rbf", device=local) as g2:
+                g2.fit(Xc, yc, grid_point(0, d)[0], grid_point(0, d)[1], Xs=Xsc)
+                mu, var = g2.predict(Xsc)
+            out["parity"] = {"mean_rel": float(abs(mu[0] - ref["fmean"][0]) / abs(ref["fmean"][0])),
+                             "var_rel": float(abs(var[0] - ref["fvar"][0]) / abs(ref["fvar"][0])), "tolerance": 1e-8}
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,7 +89,7 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
  * (north/June1st.py:210-211).  Problem b uses X + b*strideX, y + b*stridey, Xs + b*strideXs
  * (a stride of 0 shares the array between problems, e.g. one data set x many grid points).
  * RBF / Matern only.  out [batch,4], mean/var [batch,m].  Fits are pipelined over `concurrency`
- * stream sets (1..8) so one fit's panel factorisations overlap another's trailing updates. */
+ * stream sets (1..16) so one fit's panel factorisations overlap another's trailing updates. */
 int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X, int64_t strideX,
                    const double* y, int64_t stridey, const double* Xs, int64_t strideXs, int64_t n,
                    int64_t d, int64_t m, const double* ell, const double* sn_tilde, int concurrency,

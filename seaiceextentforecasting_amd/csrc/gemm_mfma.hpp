@@ -32,6 +32,8 @@ struct GemmArgs {
   // tile space in units of (TM, TN): columns bj in [c0,c1), rows bi in [max(r0, lower ? bj : r0), r1)
   int r0, r1, c0, c1;
   int lower;
+  int dbg;                     // timing ablations (debug only): 1 no global loads in loop, 2 no LDS stores, 4 no barrier
+  int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD
 };
 
 // number of tiles of the (possibly trapezoidal) tile space; shared by host and device
@@ -43,6 +45,25 @@ __host__ __device__ inline int gemm_tile_count(int r0, int r1, int c0, int c1, i
   return n;
 }
 
+// Lower (trapezoid) tile spaces are walked in 8x8-tile patches, one patch at a time per XCD: workgroups b and
+// b+8 land on the same XCD (round-robin dispatch), so the 64 tiles an XCD runs concurrently share 8 A row-blocks
+// and 8 B row-blocks and march through K together -- each K-slice is fetched into that XCD's L2 once and
+// reused 8x (column-major walking had 64 distinct A blocks per XCD: every panel read missed L2).
+// Placement only affects speed, never results.
+__host__ __device__ inline int gemm_patch_count(int r1, int c0, int c1, int PATCH) {
+  const int prmax = (r1 - c0 + PATCH - 1) / PATCH, pc = (c1 - c0 + PATCH - 1) / PATCH;
+  int n = 0;
+  for (int c = 0; c < pc && c < prmax; ++c) n += prmax - c;
+  return n;
+}
+__host__ __device__ inline int gemm_grid_size(int r0, int r1, int c0, int c1, int lower, int patch) {
+  if (r1 <= r0 || c1 <= c0) return 0;
+  if (!lower) return (r1 - r0) * (c1 - c0);
+  if (patch <= 0) return gemm_tile_count(r0, r1, c0, c1, lower);
+  const int np = gemm_patch_count(r1, c0, c1, patch);
+  return (np + 7) / 8 * 8 * patch * patch;
+}
+
 __device__ inline bool gemm_tile_coords(const GemmArgs& g, int b, int& bi, int& bj) {
   if (!g.lower) {
     int nr = g.r1 - g.r0;
@@ -50,15 +71,33 @@ __device__ inline bool gemm_tile_coords(const GemmArgs& g, int b, int& bi, int& 
     bi = g.r0 + b % nr;
     return bj < g.c1;
   }
-  int rem = b;
-  for (int c = g.c0; c < g.c1; ++c) {
-    int lo = c > g.r0 ? c : g.r0;
-    int cnt = g.r1 - lo;
-    if (cnt <= 0) continue;
-    if (rem < cnt) { bj = c; bi = lo + rem; return true; }
-    rem -= cnt;
+  if (g.patch <= 0) {
+    int rem = b;
+    for (int c = g.c0; c < g.c1; ++c) {
+      int lo = c > g.r0 ? c : g.r0;
+      int cnt = g.r1 - lo;
+      if (cnt <= 0) continue;
+      if (rem < cnt) { bj = c; bi = lo + rem; return true; }
+      rem -= cnt;
+    }
+    return false;
   }
-  return false;
+  // lower, patched: rows effectively start at the column (r0 <= c0 for every caller)
+  const int PATCH = g.patch;
+  const int xcd = b & 7, s = b >> 3;
+  int P = (s / (PATCH * PATCH)) * 8 + xcd;
+  const int w = s % (PATCH * PATCH);
+  const int prmax = (g.r1 - g.c0 + PATCH - 1) / PATCH, pcn = (g.c1 - g.c0 + PATCH - 1) / PATCH;
+  int pc = 0, pr = -1;
+  for (; pc < pcn && pc < prmax; ++pc) {
+    const int cnt = prmax - pc;
+    if (P < cnt) { pr = pc + P; break; }
+    P -= cnt;
+  }
+  if (pr < 0) return false;
+  bj = g.c0 + pc * PATCH + (w % PATCH);
+  bi = g.c0 + pr * PATCH + (w / PATCH);
+  return bj < g.c1 && bi < g.r1 && bi >= bj && bi >= g.r0;
 }
 
 template <int TM, int TN, bool BT>
@@ -144,7 +183,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst) SIGP_GLOAD((s + 1) * KT);
+    if (s + 1 < nst && !(g.dbg & 1)) SIGP_GLOAD((s + 1) * KT);
     const double* Ab = As + (buf * TM + wm * WTM + lr) * LDP + lq;
     const double* Bb = BT ? Bs + (buf * KT + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDP + lq;
 #pragma unroll
@@ -159,8 +198,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < nst) SIGP_SSTORE(buf ^ 1);
-    __syncthreads();
+    if (s + 1 < nst && !(g.dbg & 2)) SIGP_SSTORE(buf ^ 1);
+    if (!(g.dbg & 4)) __syncthreads();
   }
 #undef SIGP_GLOAD
 #undef SIGP_SSTORE

@@ -19,8 +19,12 @@
 namespace sigp {
 
 constexpr int DB = 128;   // diagonal block size
-constexpr int DP = 130;   // LDS pitch (doubles)
-constexpr int DIAG_LDS_BYTES = (DB * DP + DB + 8 * 16 * 16) * (int)sizeof(double);
+constexpr int BP = 18;    // pitch (doubles) inside a 16x16 LDS block: conflict-free 8-byte MFMA fragment reads
+constexpr int BSZ = 16 * BP;
+// LDS holds only the 36 lower 16x16 blocks (block-packed) + the reciprocal diagonal: 84 KB, so the kernel can
+// share a CU with one resident trailing-update workgroup (64 KB) instead of waiting for a whole CU to drain.
+constexpr int DIAG_LDS_BYTES = (36 * BSZ + DB) * (int)sizeof(double);
+constexpr int DIAG_THREADS = 512;
 
 __device__ inline double readlane_f64(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
@@ -28,183 +32,218 @@ __device__ inline double readlane_f64(double x, int l) {
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
+__device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BSZ; }   // bj <= bi
 
-// A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace;
+// A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace whose
+// strictly-upper part is zero (zeroed once at allocation, never written here);
 // info: device word, first failing 1-based global pivot index (0 = none yet); pivot_base: global index of row 0.
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
-                                                         int* __restrict__ info, int pivot_base) {
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
+                                                                  int* __restrict__ info, int pivot_base, int skip) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* S = smem;                 // [128][130]
-  double* dinv = smem + DB * DP;    // [128] reciprocals of the diagonal of L
-  double* XD = dinv + DB;           // [8][16][16] inverses of the 16x16 diagonal blocks
+  double* S = smem;                  // 36 blocks of [16][18]
+  double* dinv = smem + 36 * BSZ;    // [128] reciprocals of the diagonal of L
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
 
-  // ---- load the block (full 128x128; only the lower triangle is meaningful) ----
-  for (int idx = tid; idx < DB * (DB / 2); idx += 256) {
-    int row = idx >> 6, cp = (idx & 63) * 2;
-    *(d2*)(S + row * DP + cp) = *(const d2*)(A + (long)row * lda + cp);
+  // ---- load the lower triangle of the block ----
+#pragma unroll
+  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
+    const int idx = tid + it * DIAG_THREADS;
+    const int row = idx >> 6, cp = (idx & 63) * 2;
+    if (cp <= row) *(d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = *(const d2*)(A + (long)row * lda + cp);
   }
   __syncthreads();
 
   // ---- factorisation, 8 steps of 16 columns ----
   for (int jb = 0; jb < 8; ++jb) {
-    const int o = jb * 16;
-    if (wave == 0) {
-      // B1: 16x16 Cholesky; lane i (mod 16) holds row i
+    double* Sjj = S + dblk(jb, jb);
+    if (wave == 0 && !(skip & 1)) {
+      // B1: 16x16 Cholesky; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by v_rsq_f64 + Goldschmidt
       double r[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = S[(o + lr) * DP + o + c];
+      for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double dj = readlane_f64(r[j], j);
         if (!(dj > 0.0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
-          if (lane == 0 && *info == 0) *info = pivot_base + o + j + 1;
+          if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
           dj = 1.0;
         }
-        const double s = sqrt(dj);
-        const double inv = 1.0 / s;
+        const double y0 = __builtin_amdgcn_rsq(dj);
+        double g = dj * y0, hh = 0.5 * y0;
+        double e = fma(-hh, g, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        e = fma(-hh, g, 0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        const double e2 = fma(-g, g, dj);
+        const double s = fma(e2, hh, g);      // sqrt(dj)
+        const double inv = hh + hh;           // 1/sqrt(dj)
         const double lij = (lr == j) ? s : r[j] * inv;
         r[j] = lij;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
           const double lcj = readlane_f64(lij, c);
-          r[c] -= lij * lcj;
+          r[c] = fma(-lij, lcj, r[c]);
         }
-        if (lane == 0) dinv[o + j] = inv;
+        if (lane == 0) dinv[jb * 16 + j] = inv;
       }
       if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) S[(o + lr) * DP + o + c] = (c <= lr) ? r[c] : 0.0;
+        for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : 0.0;
       }
     }
     __syncthreads();
     // B2: rows below: x L11^T = a   (one thread per row)
-    const int nrows = DB - (o + 16);
-    if (tid < nrows) {
-      const int row = o + 16 + tid;
+    const int nrows = DB - (jb * 16 + 16);
+    if (tid < nrows && !(skip & 2)) {
+      const int row = jb * 16 + 16 + tid;
+      double* Sr = S + dblk(row >> 4, jb) + (row & 15) * BP;
       double x[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = S[row * DP + o + c];
+      for (int c = 0; c < 16; ++c) x[c] = Sr[c];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        x[j] *= dinv[o + j];
+        x[j] *= dinv[jb * 16 + j];
 #pragma unroll
-        for (int p = j + 1; p < 16; ++p) x[p] -= x[j] * S[(o + p) * DP + o + j];
+        for (int p = j + 1; p < 16; ++p) x[p] = fma(-x[j], Sjj[p * BP + j], x[p]);
       }
 #pragma unroll
-      for (int c = 0; c < 16; ++c) S[row * DP + o + c] = x[c];
+      for (int c = 0; c < 16; ++c) Sr[c] = x[c];
     }
     __syncthreads();
-    // B3: rank-16 update of the lower tiles of the trailing (7-jb)x(7-jb) block grid
+    // B3: rank-16 update of the lower tiles of the trailing (7-jb)x(7-jb) block grid; two independent tiles per
+    // wave iteration so the MFMA dependency chain of one tile hides behind the other's
     const int nb = 7 - jb;
     const int nt = nb * (nb + 1) / 2;
-    for (int t = wave; t < nt; t += 4) {
-      int ti = 0, rem = t;
-      while (rem > ti) { rem -= ti + 1; ++ti; }   // row ti has ti+1 tiles
-      const int tj = rem;
-      const int rowb = o + 16 + ti * 16, colb = o + 16 + tj * 16;
-      d4 acc;
+    for (int t = wave; t < nt && !(skip & 4); t += 16) {
+      int ti0 = 0, rem = t;
+      while (rem > ti0) { rem -= ti0 + 1; ++ti0; }
+      const int tj0 = rem;
+      const bool two = (t + 8) < nt;
+      int ti1 = 0; rem = two ? t + 8 : t;
+      while (rem > ti1) { rem -= ti1 + 1; ++ti1; }
+      const int tj1 = rem;
+      double* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
+      double* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
+      const double* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
+      const double* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
+      d4 acc0, acc1;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = S[(rowb + lq + 4 * r) * DP + colb + lr];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const double a = -S[(rowb + lr) * DP + o + kk * 4 + lq];
-        const double b = S[(colb + lr) * DP + o + kk * 4 + lq];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+      for (int r = 0; r < 4; ++r) {
+        acc0[r] = C0[(lq + 4 * r) * BP + lr];
+        acc1[r] = C1[(lq + 4 * r) * BP + lr];
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) S[(rowb + lq + 4 * r) * DP + colb + lr] = acc[r];
+      for (int kk = 0; kk < 4; ++kk) {
+        const double a0 = -A0[lr * BP + kk * 4 + lq];
+        const double b0 = B0[lr * BP + kk * 4 + lq];
+        const double a1 = -A1[lr * BP + kk * 4 + lq];
+        const double b1 = B1[lr * BP + kk * 4 + lq];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C0[(lq + 4 * r) * BP + lr] = acc0[r];
+      if (two) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) C1[(lq + 4 * r) * BP + lr] = acc1[r];
+      }
     }
     __syncthreads();
   }
 
-  // ---- write L11 back (lower, zeros above the diagonal) ----
-  for (int idx = tid; idx < DB * (DB / 2); idx += 256) {
-    int row = idx >> 6, cp = (idx & 63) * 2;
-    d2 v = *(const d2*)(S + row * DP + cp);
-    if (cp > row) v.x = 0.0;
-    if (cp + 1 > row) v.y = 0.0;
-    *(d2*)(A + (long)row * lda + cp) = v;
+  // ---- write L11 back (lower triangle only; the strictly-upper part of the block is never read) ----
+#pragma unroll
+  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
+    const int idx = tid + it * DIAG_THREADS;
+    const int row = idx >> 6, cp = (idx & 63) * 2;
+    if (cp <= row) {
+      d2 v = *(const d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
+      if (cp + 1 > row) v.y = 0.0;
+      *(d2*)(A + (long)row * lda + cp) = v;
+    }
   }
 
-  // ---- inverse: 16x16 diagonal-block inverses (columns of inv(L_bb) by forward substitution) ----
+  if (skip & 8) return;
+  __syncthreads();   // the diagonal blocks are about to be overwritten by their inverses
+  // ---- inverse: 16x16 diagonal-block inverses in place (columns of inv(L_bb) by forward substitution) ----
   if (wave < 2) {
-    const int blk = wave * 4 + lq, c = lr, o = blk * 16;
+    const int b = wave * 4 + lq, c = lr;
+    double* Sbb = S + dblk(b, b);
     double x[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) x[i] = (i == c) ? 1.0 : 0.0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      x[i] *= dinv[o + i];
+      x[i] *= dinv[b * 16 + i];
 #pragma unroll
-      for (int p = i + 1; p < 16; ++p) x[p] -= S[(o + p) * DP + o + i] * x[i];
+      for (int p = i + 1; p < 16; ++p) x[p] = fma(-Sbb[p * BP + i], x[i], x[p]);
     }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) XD[(blk * 16 + i) * 16 + c] = x[i];
+    for (int i = 0; i < 16; ++i) Sbb[i * BP + c] = x[i];
   }
   __syncthreads();
 
   // ---- blocked in-place inverse, last block column first:  X[ib][jb] = -(sum_p X[ib][p] L[p][jb]) X[jb][jb] ----
-  for (int jb = 7; jb >= 0; --jb) {
-    const int o = jb * 16;
+  // wave w owns block row ib = jb+1+w (at most 7 rows -> one per wave)
+  for (int jb = 6; jb >= 0 && !(skip & 16); --jb) {
     const int nb = 7 - jb;
-    d4 t0 = d4{0, 0, 0, 0}, t1 = d4{0, 0, 0, 0};
-    // each wave owns block rows ib = jb+1+wave and jb+1+wave+4 (if present)
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int q = wave + 4 * slot;
-      if (q < nb) {
-        const int ib = jb + 1 + q;
-        d4 acc = d4{0, 0, 0, 0};
-        for (int p = jb + 1; p <= ib; ++p) {
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            const double a = S[(ib * 16 + lr) * DP + p * 16 + kk * 4 + lq];    // X[ib][p] (row lr, k)
-            const double b = S[(p * 16 + kk * 4 + lq) * DP + o + lr];           // L[p][jb] (k, col lr)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-          }
-        }
-        if (slot == 0) t0 = acc; else t1 = acc;
-      }
-    }
-    __syncthreads();   // every read of the original L[.][jb] is done
-#pragma unroll
-    for (int slot = 0; slot < 2; ++slot) {
-      const int q = wave + 4 * slot;
-      if (q < nb) {
-        const int ib = jb + 1 + q;
-        d4 acc = slot == 0 ? t0 : t1;
-        // park T in the (wave-private) destination block so it can be re-read in A-operand layout
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(ib * 16 + lq + 4 * r) * DP + o + lr] = acc[r];
-        d4 u = d4{0, 0, 0, 0};
+    const int ib = jb + 1 + wave;
+    d4 acc = d4{0, 0, 0, 0}, accb = d4{0, 0, 0, 0};
+    if (wave < nb) {
+      // two interleaved accumulation chains (even / odd p)
+      for (int p = jb + 1; p <= ib; p += 2) {
+        const bool hasb = (p + 1) <= ib;
+        const int pb = hasb ? p + 1 : p;
+        const double* Xa = S + dblk(ib, p), *La = S + dblk(p, jb);
+        const double* Xb = S + dblk(ib, pb), *Lb = S + dblk(pb, jb);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const double a = -S[(ib * 16 + lr) * DP + o + kk * 4 + lq];
-          const double b = XD[(jb * 16 + kk * 4 + lq) * 16 + lr];
-          u = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, u, 0, 0, 0);
+          const double a = Xa[lr * BP + kk * 4 + lq];      // X[ib][p] (row lr, k)
+          const double b = La[(kk * 4 + lq) * BP + lr];    // L[p][jb] (k, col lr)
+          double a2 = Xb[lr * BP + kk * 4 + lq];
+          const double b2 = Lb[(kk * 4 + lq) * BP + lr];
+          if (!hasb) a2 = 0.0;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+          accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accb, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) S[(ib * 16 + lq + 4 * r) * DP + o + lr] = u[r];
       }
+      acc += accb;
     }
-    // diagonal block of the inverse
-    {
-      const int i = tid >> 4, c = tid & 15;   // 256 threads = 16x16
-      S[(o + i) * DP + o + c] = XD[(jb * 16 + i) * 16 + c];
+    __syncthreads();   // every read of the original L[.][jb] is done
+    if (wave < nb) {
+      // park T in the (wave-private) destination block so it can be re-read in A-operand layout
+      double* D = S + dblk(ib, jb);
+      const double* Xjj = S + dblk(jb, jb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[(lq + 4 * r) * BP + lr] = acc[r];
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("" ::: "memory");
+      d4 u = d4{0, 0, 0, 0};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const double a = -D[lr * BP + kk * 4 + lq];
+        const double b = Xjj[(kk * 4 + lq) * BP + lr];
+        u = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, u, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) D[(lq + 4 * r) * BP + lr] = u[r];
     }
     __syncthreads();
   }
 
-  // ---- write inv(L11) (lower, zeros above) ----
-  for (int idx = tid; idx < DB * (DB / 2); idx += 256) {
-    int row = idx >> 6, cp = (idx & 63) * 2;
-    d2 v = *(const d2*)(S + row * DP + cp);
-    if (cp > row) v.x = 0.0;
-    if (cp + 1 > row) v.y = 0.0;
-    *(d2*)(Linv + row * DB + cp) = v;
+  // ---- write inv(L11) (lower triangle) ----
+#pragma unroll
+  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
+    const int idx = tid + it * DIAG_THREADS;
+    const int row = idx >> 6, cp = (idx & 63) * 2;
+    if (cp <= row) {
+      d2 v = *(const d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
+      if (cp + 1 > row) v.y = 0.0;
+      *(d2*)(Linv + row * DB + cp) = v;
+    }
   }
 }
 

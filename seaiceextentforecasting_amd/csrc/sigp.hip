@@ -7,7 +7,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -15,6 +17,7 @@
 #include "gemm_mfma.hpp"
 #include "kernels_misc.hpp"
 #include "potrf_diag.hpp"
+#include "syrk128.hpp"
 
 using namespace sigp;
 
@@ -22,7 +25,7 @@ namespace {
 
 constexpr int NB = 128;         // column-block width of the factorisation (= diagonal block)
 constexpr int RIDE = 128;       // rows of the ride-along block
-constexpr int MAX_SLOTS = 8;
+constexpr int MAX_SLOTS = 16;
 
 struct ProfEvent { hipEvent_t a, b; int kclass; };
 
@@ -73,6 +76,11 @@ struct sigp_handle {
   int opt_outer = 2;       // outer panel width in 128-blocks
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
+  int opt_pan_priority = 1;  // panel streams at high priority
+  int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
+  int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
+  int opt_host_timing = 0;   // print host enqueue time per batch_run (debug)
+  int opt_reserve_cus = 2;   // CUs masked out of the update streams so the panel chain always finds a free CU
   // profiling
   bool prof = false;
   std::vector<ProfEvent> pev;
@@ -112,12 +120,32 @@ int ensure(sigp_handle* h, double** p, long* cap, long need) {
   return SIGP_OK;
 }
 
+// update stream: every CU except the last `reserve` ones (the 150 KB-LDS diagonal kernel of the panel stream
+// otherwise waits for a whole CU to drain under the trailing update: measured 170 us instead of 55 us)
+int make_update_stream(sigp_handle* h, hipStream_t* st) {
+  int ncu = 0;
+  HIPCHK(h, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, h->device));
+  const int reserve = std::min(h->opt_reserve_cus, ncu / 2);
+  if (reserve <= 0) {
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIPCHK(h, hipStreamCreateWithPriority(st, hipStreamNonBlocking, lo));
+    return SIGP_OK;
+  }
+  const int words = (ncu + 31) / 32;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int i = 0; i < ncu - reserve; ++i) mask[i / 32] |= (1u << (i % 32));
+  HIPCHK(h, hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask.data()));
+  return SIGP_OK;
+}
+
 int slot_init(sigp_handle* h, Slot& s) {
   if (s.s_upd) return SIGP_OK;
   int lo = 0, hi = 0;
   HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-  HIPCHK(h, hipStreamCreateWithPriority(&s.s_upd, hipStreamNonBlocking, lo));
-  HIPCHK(h, hipStreamCreateWithPriority(&s.s_pan, hipStreamNonBlocking, hi));
+  int rc = make_update_stream(h, &s.s_upd);
+  if (rc) return rc;
+  HIPCHK(h, hipStreamCreateWithPriority(&s.s_pan, hipStreamNonBlocking, h->opt_pan_priority ? hi : lo));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_pan, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_la, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
@@ -137,6 +165,8 @@ int slot_reserve(sigp_handle* h, Slot& s, long n_pad) {
   s.mat = nullptr; s.dinv = nullptr; s.cap_npad = 0;
   HIPCHK(h, hipMalloc((void**)&s.mat, (size_t)(n_pad + RIDE) * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&s.dinv, (size_t)(n_pad / NB) * NB * NB * sizeof(double)));
+  HIPCHK(h, hipMemset(s.dinv, 0, (size_t)(n_pad / NB) * NB * NB * sizeof(double)));   // strictly-upper parts stay zero
+  HIPCHK(h, hipDeviceSynchronize());
   s.cap_npad = n_pad;
   return SIGP_OK;
 }
@@ -185,7 +215,7 @@ void prof_drain(sigp_handle* h) {
 // ---- GEMM launch ----------------------------------------------------------------------------------
 template <int TM, int TN, int WM, int WN, int MODE, bool BT>
 int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
-  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
+  const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
   auto kern = gemm_mfma_kernel<TM, TN, WM, WN, MODE, BT>;
   constexpr int lds = gemm_lds_bytes<TM, TN, BT>();
@@ -199,11 +229,24 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
   return SIGP_OK;
 }
 
+int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
+  const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
+  if (nt <= 0) return SIGP_OK;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(syrk128_kernel, dim3(nt), dim3(256), SY_LDS_BYTES, st, g);
+  HIPCHK(h, hipGetLastError());
+  return SIGP_OK;
+}
+
 // C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
 int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
   const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
   if (nt <= 0) return SIGP_OK;
-  if (nt >= h->opt_small_tiles) return launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+  if (nt >= h->opt_small_tiles) return h->opt_syrk_v2 ? launch_syrk128(h, st, g) : launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
   g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
   return launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
 }
@@ -254,52 +297,49 @@ int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
     HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
   }
 
-  auto panel = [&](int J, int Wc) -> int {
-    for (int i = 0; i < Wc; ++i) {
-      const int c = J + i;
+  // lower-trapezoid update  C[cols ccol0..ccol1, rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
+  auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1) -> int {
+    const long o = (long)ccol0 * NB;
+    GemmArgs g{};
+    g.A = M + o * ld + (long)kcol0 * NB; g.lda = ld;
+    g.B = g.A; g.ldb = ld;
+    g.C = M + o * ld + o; g.ldc = ld;
+    g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
+    const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
+    if (nt <= 0) return SIGP_OK;
+    ProfScope ps(h, st, kclass, nt * 2.0 * NB * NB * g.K, nt * 2.0 * NB * NB * 8);
+    return gemm_sub_auto(h, st, g);
+  };
+  // factor block columns [J0, J0+Wp) (already up to date) by binary recursion: the left half, a rank-(half) update
+  // of the right half's columns, then the right half.  Every update inside a panel of width Wp has K >= 128 and
+  // touches only that panel's columns, so most of the panel-internal flops also run at large K.
+  std::function<int(int, int)> panel = [&](int J0, int Wp) -> int {
+    if (Wp == 1) {
+      const int c = J0;
       {
         ProfScope ps(h, sp, SIGP_KC_DIAG, 2.0 * NB * NB * NB / 3, 3.0 * NB * NB * 8);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
-                           s.dinv + (long)c * NB * NB, s.info, c * NB);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
+                           s.dinv + (long)c * NB * NB, s.info, c * NB, 0);
         HIPCHK(h, hipGetLastError());
       }
       const long o = (long)(c + 1) * NB;
       const int rows_below = R - (c + 1);   // 128-row blocks below the diagonal block (ride block included)
-      {
-        GemmArgs g{};
-        g.A = M + o * ld + (long)c * NB; g.lda = ld;
-        g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
-        g.C = M + o * ld + (long)c * NB; g.ldc = ld;
-        g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
-        ProfScope ps(h, sp, SIGP_KC_TRSM, 2.0 * rows_below * NB * NB * NB, 2.0 * rows_below * NB * NB * 8);
-        int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
-        if (rc) return rc;
-      }
-      if (i < Wc - 1) {
-        GemmArgs g{};
-        g.A = M + o * ld + (long)c * NB; g.lda = ld;
-        g.B = g.A; g.ldb = ld;
-        g.C = M + o * ld + o; g.ldc = ld;
-        g.K = NB; g.r0 = 0; g.r1 = rows_below; g.c0 = 0; g.c1 = J + Wc - 1 - c; g.lower = 1;
-        const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
-        ProfScope ps(h, sp, SIGP_KC_UPDATE_INNER, nt * 2.0 * NB * NB * NB, nt * 2.0 * NB * NB * 8);
-        int rc = gemm_sub_auto(h, sp, g);
-        if (rc) return rc;
-      }
+      GemmArgs g{};
+      g.A = M + o * ld + (long)c * NB; g.lda = ld;
+      g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
+      g.C = M + o * ld + (long)c * NB; g.ldc = ld;
+      g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+      ProfScope ps(h, sp, SIGP_KC_TRSM, 2.0 * rows_below * NB * NB * NB, 2.0 * rows_below * NB * NB * 8);
+      return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
     }
-    return SIGP_OK;
+    const int hw = Wp / 2;
+    int rc = panel(J0, hw);
+    if (rc) return rc;
+    if ((rc = update(sp, SIGP_KC_UPDATE_INNER, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
+    return panel(J0 + hw, Wp - hw);
   };
   auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
-    const long o = (long)(J + Wc) * NB;
-    GemmArgs g{};
-    g.A = M + o * ld + (long)J * NB; g.lda = ld;
-    g.B = g.A; g.ldb = ld;
-    g.C = M + o * ld + o; g.ldc = ld;
-    g.K = Wc * NB; g.r0 = 0; g.r1 = R - (J + Wc); g.c0 = c0; g.c1 = c1; g.lower = 1;
-    const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
-    if (nt <= 0) return SIGP_OK;
-    ProfScope ps(h, st, SIGP_KC_UPDATE_OUTER, nt * 2.0 * NB * NB * g.K, nt * 2.0 * NB * NB * 8);
-    return gemm_sub_auto(h, st, g);
+    return update(st, SIGP_KC_UPDATE_OUTER, J, Wc, J + Wc, c0, c1);
   };
 
   int rc = panel(0, std::min(W, T));
@@ -412,8 +452,41 @@ const char* sigp_last_error(const sigp_handle* h) { return h ? h->err.c_str() : 
 
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!h || !name) return SIGP_BAD_ARG;
-  if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 16) return SIGP_BAD_ARG; h->opt_outer = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_outer = (int)value; return SIGP_OK; }
   if (!strcmp(name, "lookahead")) { h->opt_lookahead = value ? 1 : 0; return SIGP_OK; }
+  if (!strcmp(name, "pan_priority")) {
+    if ((int)(value != 0) == h->opt_pan_priority) return SIGP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->opt_pan_priority = value ? 1 : 0;
+    int lo = 0, hi = 0;
+    HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    for (auto& s : h->slots) {
+      if (!s.s_pan) continue;
+      HIPCHK(h, hipStreamDestroy(s.s_pan));
+      s.s_pan = nullptr;
+      HIPCHK(h, hipStreamCreateWithPriority(&s.s_pan, hipStreamNonBlocking, h->opt_pan_priority ? hi : lo));
+    }
+    return SIGP_OK;
+  }
+  if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
+  if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "reserve_cus")) {
+    if (value < 0 || value > 64) return SIGP_BAD_ARG;
+    if ((int)value == h->opt_reserve_cus) return SIGP_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    h->opt_reserve_cus = (int)value;
+    for (auto& s : h->slots) {
+      if (!s.s_upd) continue;
+      HIPCHK(h, hipStreamDestroy(s.s_upd));
+      s.s_upd = nullptr;
+      int rc = make_update_stream(h, &s.s_upd);
+      if (rc) return rc;
+    }
+    return SIGP_OK;
+  }
   if (!strcmp(name, "small_tile_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_small_tiles = (int)value; return SIGP_OK; }
   return fail(h, SIGP_BAD_ARG, "unknown option %s", name);
 }
@@ -821,7 +894,7 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
                    int concurrency, double* out, double* mean, double* var) {
   if (!h || h->b_count == 0 || first < 0 || count < 1 || !ell || !sn_tilde || !out) return fail(h, SIGP_BAD_ARG, "batch_run: bad argument");
   if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "batch_run: RBF / MATERN52 only");
-  if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..8");
+  if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..16");
   HIPCHK(h, hipSetDevice(h->device));
   const long n = h->b_n, d = h->b_d, dp = h->b_dp, m = h->b_m, n_pad = h->b_npad;
   int rc;
@@ -840,9 +913,13 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     inflight[k] = -1;
     return SIGP_OK;
   };
+  double enq_ms = 0, wait_ms = 0;
   for (long i = 0; i < count; ++i) {
     const int k = (int)(i % concurrency);
+    auto tw0 = std::chrono::steady_clock::now();
     if (inflight[k] >= 0 && (rc = retire(k))) return rc;
+    auto tw1 = std::chrono::steady_clock::now();
+    wait_ms += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
     Slot& s = h->slots[k];
     const long b = (first + i) % h->b_count;
     KParams kp;
@@ -852,7 +929,10 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     if ((rc = potrf_slot(h, s, n_pad))) return rc;
     if ((rc = epilogue_slot(h, s, n, n_pad, m))) return rc;
     inflight[k] = i; snv[k] = sn_tilde[i];
+    enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
   }
+  if (h->opt_host_timing)
+    fprintf(stderr, "[sigp] batch_run: %ld fits, host enqueue %.3f ms/fit, host wait-on-retire %.3f ms/fit\n", (long)count, enq_ms / count, wait_ms / count);
   for (int k = 0; k < concurrency; ++k)
     if (inflight[k] >= 0 && (rc = retire(k))) return rc;
   // slot 0 no longer holds the single-fit state
@@ -905,6 +985,169 @@ int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* laun
   if (launches) *launches = h->p_n[kclass];
   if (flops) *flops = h->p_flops[kclass];
   if (bytes) *bytes = h->p_bytes[kclass];
+  return SIGP_OK;
+}
+
+// fp64 MFMA issue-rate probe: nothing but v_mfma_f64_16x16x4_f64 on 16 independent accumulators per wave
+__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double* out, int iters, double seed) {
+  sigp::d4 acc[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = sigp::d4{0.0, 0.0, 0.0, 0.0};
+  double a[8], b[8];
+  unsigned long long x = 88172645463325252ull + threadIdx.x * 2654435761ull + blockIdx.x * 97ull;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {   // seed < 0: full-range pseudo-random operands (data toggling); else constants
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    a[i] = seed < 0 ? (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5 : seed + threadIdx.x * 1e-3;
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    b[i] = seed < 0 ? (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5 : seed - threadIdx.x * 1e-3;
+  }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 7], b[(i + (i >> 3)) & 7], acc[i], 0, 0, 0);
+  }
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+__global__ void whereami_kernel(unsigned* out) {
+  // hold the CU for a while so that blocks spread over every CU the mask allows
+  long long t0 = clock64();
+  while (clock64() - t0 < 200000) {}
+  if (threadIdx.x == 0) {
+    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID, 32 bits
+    unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+    out[2 * blockIdx.x] = xcc;
+    out[2 * blockIdx.x + 1] = hwid;
+  }
+}
+
+// ---- debug / micro-benchmark entry points (not part of the product ABI; see tools/) -------------------
+int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps, double* ms_avg, double* L_out, double* Linv_out) {
+  if (!h || !A128 || reps < 1) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  double *a0, *a1, *li; int* info;
+  HIPCHK(h, hipMalloc((void**)&a0, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&a1, NB * NB * 8));
+  HIPCHK(h, hipMalloc((void**)&li, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&info, 4));
+  HIPCHK(h, hipMemset(li, 0, NB * NB * 8));
+  HIPCHK(h, hipMemcpy(a0, A128, NB * NB * 8, hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemset(info, 0, 4));
+  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  hipStream_t st = h->slots[0].s_upd;
+  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  double tot = 0;
+  for (int r = 0; r < reps + 2; ++r) {
+    HIPCHK(h, hipMemcpyAsync(a1, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(h, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip);
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) tot += ms;
+  }
+  if (ms_avg) *ms_avg = tot / reps;
+  if (L_out) HIPCHK(h, hipMemcpy(L_out, a1, NB * NB * 8, hipMemcpyDeviceToHost));
+  if (Linv_out) HIPCHK(h, hipMemcpy(Linv_out, li, NB * NB * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(a0); (void)hipFree(a1); (void)hipFree(li); (void)hipFree(info);
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return SIGP_OK;
+}
+
+int sigp_debug_mfma_peak(sigp_handle* h, int blocks, int iters, double* tflops, double seed) {
+  if (!h || blocks < 1 || iters < 1) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  double* out; HIPCHK(h, hipMalloc((void**)&out, (size_t)blocks * 256 * 8));
+  hipStream_t st = h->slots[0].s_pan;
+  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < 5; ++r) {
+    HIPCHK(h, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters, seed);
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best) best = ms;
+  }
+  if (tflops) *tflops = (double)blocks * 4 * iters * 16 * 2048.0 / (best * 1e-3) / 1e12;
+  (void)hipFree(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return SIGP_OK;
+}
+
+// time the lower-tile update C -= P P^T (128x128 tiles) on a synthetic (rt*128) x K panel, tile walk `patch`
+int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg) {
+  if (!h || rt < 1 || K < 16 || reps < 1) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const long n = (long)rt * NB, ldp = K, ldc = n;
+  double *P, *Cm;
+  HIPCHK(h, hipMalloc((void**)&P, (size_t)n * K * 8)); HIPCHK(h, hipMalloc((void**)&Cm, (size_t)n * n * 8));
+  HIPCHK(h, hipMemset(Cm, 0, (size_t)n * n * 8));
+  std::vector<double> hp((size_t)n * K);
+  for (size_t i = 0; i < hp.size(); ++i) hp[i] = 1e-3 * (double)((i * 2654435761u) % 1000) - 0.5;
+  HIPCHK(h, hipMemcpy(P, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
+  hipStream_t st = h->slots[0].s_pan;
+  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  GemmArgs g{};
+  g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp; g.C = Cm; g.ldc = ldc; g.K = K; g.r0 = 0; g.r1 = rt; g.c0 = 0; g.c1 = rt; g.lower = 1; g.patch = patch; g.dbg = dbg;
+  if (small == 1) { g.r1 *= 2; g.c1 *= 2; }
+  double tot = 0;
+  for (int r = 0; r < reps + 2; ++r) {
+    HIPCHK(h, hipEventRecord(e0, st));
+    int rc = small == 1 ? launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g) : small == 2 ? launch_syrk128(h, st, g) : launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+    if (rc) return rc;
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) tot += ms;
+  }
+  const double nt = (double)rt * (rt + 1) / 2;
+  if (ms_avg) *ms_avg = tot / reps;
+  if (tflops) *tflops = nt * 2.0 * NB * NB * K / (tot / reps * 1e-3) / 1e12;
+  (void)hipFree(P); (void)hipFree(Cm); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return SIGP_OK;
+}
+
+// do independent small kernels on different streams of this handle overlap?  returns wall ms for nstreams x reps launches
+int sigp_debug_stream_concurrency(sigp_handle* h, int nstreams, int reps, int blocks, int iters, int use_slot_streams, double* ms_out) {
+  if (!h || nstreams < 1 || nstreams > 16) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<hipStream_t> st((size_t)nstreams);
+  for (int i = 0; i < nstreams; ++i) {
+    if (use_slot_streams) {
+      int rc = slot_init(h, h->slots[i / 2]);
+      if (rc) return rc;
+      st[i] = (i & 1) ? h->slots[i / 2].s_pan : h->slots[i / 2].s_upd;
+    } else {
+      HIPCHK(h, hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
+    }
+  }
+  double* out; HIPCHK(h, hipMalloc((void**)&out, (size_t)nstreams * blocks * 256 * 8));
+  HIPCHK(h, hipDeviceSynchronize());
+  auto t0 = std::chrono::steady_clock::now();
+  for (int r = 0; r < reps; ++r)
+    for (int i = 0; i < nstreams; ++i)
+      hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st[i], out + (size_t)i * blocks * 256, iters, 0.25);
+  HIPCHK(h, hipDeviceSynchronize());
+  if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (!use_slot_streams) for (auto q : st) (void)hipStreamDestroy(q);
+  (void)hipFree(out);
+  return SIGP_OK;
+}
+
+// which XCC / CU does CU-mask bit `bit` select?  out[0] = XCC_ID reg, out[1] = HW_ID reg of a 1-block kernel
+int sigp_debug_cumask_probe(sigp_handle* h, const unsigned* mask8, int blocks, unsigned* out2) {
+  if (!h || !mask8 || blocks < 1 || !out2) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st;
+  HIPCHK(h, hipExtStreamCreateWithCUMask(&st, 8, mask8));
+  unsigned* d; HIPCHK(h, hipMalloc((void**)&d, (size_t)blocks * 8));
+  HIPCHK(h, hipMemset(d, 0xff, (size_t)blocks * 8));
+  HIPCHK(h, hipDeviceSynchronize());
+  hipLaunchKernelGGL(whereami_kernel, dim3(blocks), dim3(64), 0, st, d);
+  HIPCHK(h, hipStreamSynchronize(st));
+  HIPCHK(h, hipMemcpy(out2, d, (size_t)blocks * 8, hipMemcpyDeviceToHost));
+  (void)hipFree(d); (void)hipStreamDestroy(st);
   return SIGP_OK;
 }
 

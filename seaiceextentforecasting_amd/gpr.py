@@ -28,7 +28,7 @@ class LinAlgError(np.linalg.LinAlgError):
 
 
 class GPR:
-    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None):
+    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
         if dtype != "f64":
@@ -50,6 +50,8 @@ class GPR:
             self.set_option("outer_blocks", outer_blocks)
         if lookahead is not None:
             self.set_option("lookahead", int(bool(lookahead)))
+        if reserve_cus is not None:
+            self.set_option("reserve_cus", reserve_cus)
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc, what):
