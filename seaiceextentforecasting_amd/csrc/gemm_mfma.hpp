@@ -29,9 +29,12 @@ struct GemmArgs {
   const double* B; long ldb;   // B is N x K row-major (BT=false) or K x N row-major (BT=true)
   double* C; long ldc;
   int K;                       // multiple of 16
+  int batch;                   // grid.y (0 or 1 = single problem)
+  long sA, sB, sC;             // batch strides (elements): blockIdx.y selects the batch member
   // tile space in units of (TM, TN): columns bj in [c0,c1), rows bi in [max(r0, lower ? bj : r0), r1)
   int r0, r1, c0, c1;
   int lower;
+  unsigned long long* stamp;   // debug: per-workgroup {s_memtime, s_memrealtime} deltas over the kernel body (nullptr = off)
   int dbg;                     // timing ablations (debug only): 1 no global loads in loop, 2 no LDS stores, 4 no barrier
   int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD
 };
@@ -125,9 +128,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 
   int bi, bj;
   if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
-  const double* Ag = g.A + (long)bi * TM * g.lda;
-  const double* Bg = BT ? g.B + (long)bj * TN : g.B + (long)bj * TN * g.ldb;
-  double* Cg = g.C + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
+  const long bz = blockIdx.y;
+  const double* Ag = g.A + bz * g.sA + (long)bi * TM * g.lda;
+  const double* Bg = BT ? g.B + bz * g.sB + (long)bj * TN : g.B + bz * g.sB + (long)bj * TN * g.ldb;
+  double* Cg = g.C + bz * g.sC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
 
   d4 acc[FM][FN];
 #pragma unroll

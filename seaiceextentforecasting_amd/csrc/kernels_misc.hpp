@@ -11,6 +11,7 @@ enum { KID_NETDIFFUSION = 0, KID_RBF = 1, KID_MATERN52 = 2 };
 
 struct KParams {
   int kernel_id;
+  int ds;           // data-set index of this batch member (X + ds*strideX, y + ds*stridey, Xs + ds*strideXs)
   double c_rbf;     // -0.5 / ell^2
   double inv_ell;   // 1 / ell
   double sn;        // sigma_n tilde (added on the diagonal)
@@ -27,10 +28,15 @@ __device__ inline double cov_from_sq(const KParams& kp, double sq) {
 // X is [n_pad][dp] row-major, zero padded.  Each wave writes two 512-B row segments per store (16 B per lane).
 constexpr int KB_T = 64;    // tile
 constexpr int KB_DC = 32;   // feature chunk staged in LDS
-__global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, int dp, int d, int n,
-                                                     double* __restrict__ Mat, long ld, KParams kp) {
+// blockIdx.z = batch member; its hyper-parameters and data set come from kps[z].
+__global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
+                                                     double* __restrict__ Mat, long strideM, long ld,
+                                                     const KParams* __restrict__ kps) {
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi) return;
+  const KParams kp = kps[blockIdx.z];
+  X += kp.ds * strideX;
+  Mat += blockIdx.z * strideM;
   __shared__ double Xi[KB_T][KB_DC + 1];
   __shared__ __attribute__((aligned(16))) double XjT[KB_DC][KB_T + 2];
   const int tid = threadIdx.x;
@@ -81,13 +87,18 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
 // Ride-along block (128 rows x n_pad): row 0 = y (may be null -> zeros), rows 1..m = k~(xs_j, x_i)
 // (north/June1st.py:272 KXXs^T in unit signal variance), remaining rows 0.  first_row lets predict()
 // fill rows 0..m-1 with cross-covariances only (y == nullptr, first_row = 0).
-__global__ __launch_bounds__(256) void ride_build_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
-                                                         const double* __restrict__ y, int dp, int d, int n, int n_pad,
-                                                         int m, int first_row, double* __restrict__ Z, long ld,
-                                                         KParams kp, int compute_cov) {
+__global__ __launch_bounds__(256) void ride_build_kernel(const double* __restrict__ X, long strideX, const double* __restrict__ Xs,
+                                                         long strideXs, const double* __restrict__ y, long stridey, int dp, int d,
+                                                         int n, int n_pad, int m, int first_row, double* __restrict__ Z,
+                                                         long strideZ, long ld, const KParams* __restrict__ kps, int compute_cov) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // column (training point)
   const int r = blockIdx.y;                       // row of the ride block
   if (i >= n_pad) return;
+  const KParams kp = kps[blockIdx.z];
+  X += kp.ds * strideX;
+  Xs += kp.ds * strideXs;
+  if (y != nullptr) y += kp.ds * stridey;
+  Z += blockIdx.z * strideZ;
   double v = 0.0;
   if (i < n) {
     if (y != nullptr && r == 0) {
@@ -139,11 +150,16 @@ __device__ inline double block_reduce_sum(double v, double* sh) {
 //   res[128 + r] = W[r] . W[r]      (v^T v of north/June1st.py:277)
 //   res[256]     = sum_i<n log L~_ii (north/June1st.py:246)
 // grid = nrows + 1 blocks of 256 threads.
+// blockIdx.y = batch member (strides sW, sZ, sM; res += 512*y).
 __global__ __launch_bounds__(256) void epilogue_kernel(const double* __restrict__ W, long ldw, const double* __restrict__ zrow,
                                                        const double* __restrict__ Mat, long ld, int n, int n_pad, int nrows,
-                                                       double* __restrict__ res) {
+                                                       double* __restrict__ res, long sW, long sZ, long sM) {
   __shared__ double sh[4];
   const int r = blockIdx.x;
+  W += blockIdx.y * sW;
+  zrow += blockIdx.y * sZ;
+  if (Mat != nullptr) Mat += blockIdx.y * sM;
+  res += blockIdx.y * 512;
   if (r < nrows) {
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n_pad; i += 256) {

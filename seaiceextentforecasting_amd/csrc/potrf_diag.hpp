@@ -37,8 +37,13 @@ __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * B
 // A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace whose
 // strictly-upper part is zero (zeroed once at allocation, never written here);
 // info: device word, first failing 1-based global pivot index (0 = none yet); pivot_base: global index of row 0.
+// blockIdx.x = batch member: A += b*strideA, Linv += b*strideL, info += b.
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
-                                                                  int* __restrict__ info, int pivot_base, int skip) {
+                                                                  int* __restrict__ info, int pivot_base, int skip, long strideA,
+                                                                  long strideL) {
+  A += blockIdx.x * strideA;
+  Linv += blockIdx.x * strideL;
+  info += blockIdx.x;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* S = smem;                  // 36 blocks of [16][18]
   double* dinv = smem + 36 * BSZ;    // [128] reciprocals of the diagonal of L

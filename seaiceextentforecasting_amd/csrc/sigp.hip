@@ -32,13 +32,17 @@ struct ProfEvent { hipEvent_t a, b; int kclass; };
 // One "slot" = everything one in-flight fit needs: the augmented matrix, inverse diagonal blocks, two
 // streams (update / panel) and result buffers.  Slot 0 backs the single-fit API.
 struct Slot {
-  double* mat = nullptr;      // [(n_pad + RIDE)][n_pad]: K~ -> L~ (lower) and the ride rows below it
-  double* dinv = nullptr;     // [T][128][128] inverses of the diagonal blocks
-  double* res = nullptr;      // device [512]: epilogue reductions
-  double* res_host = nullptr; // pinned [512]
-  int* info = nullptr;        // device
-  int* info_host = nullptr;   // pinned
+  int capB = 0;               // batch capacity: fits factorised in lockstep by this slot
   long cap_npad = 0;
+  long matStride = 0, dinvStride = 0;   // per-member strides (elements) for the current n_pad
+  double* mat = nullptr;      // [capB][(n_pad + RIDE)][n_pad]: K~ -> L~ (lower) and the ride rows below it
+  double* dinv = nullptr;     // [capB][T][128][128] inverses of the diagonal blocks (strictly-upper parts stay zero)
+  double* res = nullptr;      // device [capB][512]: epilogue reductions
+  double* res_host = nullptr; // pinned
+  int* info = nullptr;        // device [capB]
+  int* info_host = nullptr;   // pinned
+  KParams* kps = nullptr;     // device [capB] per-member hyper-parameters / data-set index
+  KParams* kps_host = nullptr;// pinned
   hipStream_t s_upd = nullptr, s_pan = nullptr;
   hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
 };
@@ -79,6 +83,7 @@ struct sigp_handle {
   int opt_pan_priority = 1;  // panel streams at high priority
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
+  int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
   int opt_host_timing = 0;   // print host enqueue time per batch_run (debug)
   int opt_reserve_cus = 2;   // CUs masked out of the update streams so the panel chain always finds a free CU
   // profiling
@@ -149,35 +154,49 @@ int slot_init(sigp_handle* h, Slot& s) {
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_pan, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_la, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
-  HIPCHK(h, hipMalloc((void**)&s.res, 512 * sizeof(double)));
-  HIPCHK(h, hipHostMalloc((void**)&s.res_host, 512 * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&s.info, sizeof(int)));
-  HIPCHK(h, hipHostMalloc((void**)&s.info_host, sizeof(int)));
   return SIGP_OK;
 }
 
-int slot_reserve(sigp_handle* h, Slot& s, long n_pad) {
-  int rc = slot_init(h, s);
-  if (rc) return rc;
-  if (s.cap_npad >= n_pad) return SIGP_OK;
-  if (s.mat) HIPCHK(h, hipFree(s.mat));
-  if (s.dinv) HIPCHK(h, hipFree(s.dinv));
-  s.mat = nullptr; s.dinv = nullptr; s.cap_npad = 0;
-  HIPCHK(h, hipMalloc((void**)&s.mat, (size_t)(n_pad + RIDE) * n_pad * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&s.dinv, (size_t)(n_pad / NB) * NB * NB * sizeof(double)));
-  HIPCHK(h, hipMemset(s.dinv, 0, (size_t)(n_pad / NB) * NB * NB * sizeof(double)));   // strictly-upper parts stay zero
-  HIPCHK(h, hipDeviceSynchronize());
-  s.cap_npad = n_pad;
-  return SIGP_OK;
-}
-
-void slot_free(Slot& s) {
+void slot_free_buffers(Slot& s) {
   if (s.mat) (void)hipFree(s.mat);
   if (s.dinv) (void)hipFree(s.dinv);
   if (s.res) (void)hipFree(s.res);
   if (s.res_host) (void)hipHostFree(s.res_host);
   if (s.info) (void)hipFree(s.info);
   if (s.info_host) (void)hipHostFree(s.info_host);
+  if (s.kps) (void)hipFree(s.kps);
+  if (s.kps_host) (void)hipHostFree(s.kps_host);
+  s.mat = s.dinv = s.res = s.res_host = nullptr; s.info = s.info_host = nullptr; s.kps = s.kps_host = nullptr;
+  s.capB = 0; s.cap_npad = 0;
+}
+
+// make room for B lockstep members of padded order n_pad
+int slot_reserve(sigp_handle* h, Slot& s, long n_pad, int B) {
+  int rc = slot_init(h, s);
+  if (rc) return rc;
+  s.matStride = (n_pad + RIDE) * n_pad;
+  s.dinvStride = (n_pad / NB) * NB * NB;
+  if (s.cap_npad >= n_pad && s.capB >= B) return SIGP_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  const long np = std::max(n_pad, s.cap_npad);
+  const int nb = std::max(B, s.capB);
+  slot_free_buffers(s);
+  HIPCHK(h, hipMalloc((void**)&s.mat, (size_t)nb * (np + RIDE) * np * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&s.dinv, (size_t)nb * (np / NB) * NB * NB * sizeof(double)));
+  HIPCHK(h, hipMemset(s.dinv, 0, (size_t)nb * (np / NB) * NB * NB * sizeof(double)));   // strictly-upper parts stay zero
+  HIPCHK(h, hipMalloc((void**)&s.res, (size_t)nb * 512 * sizeof(double)));
+  HIPCHK(h, hipHostMalloc((void**)&s.res_host, (size_t)nb * 512 * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&s.info, (size_t)nb * sizeof(int)));
+  HIPCHK(h, hipHostMalloc((void**)&s.info_host, (size_t)nb * sizeof(int)));
+  HIPCHK(h, hipMalloc((void**)&s.kps, (size_t)nb * sizeof(KParams)));
+  HIPCHK(h, hipHostMalloc((void**)&s.kps_host, (size_t)nb * sizeof(KParams)));
+  HIPCHK(h, hipDeviceSynchronize());
+  s.cap_npad = np; s.capB = nb;
+  return SIGP_OK;
+}
+
+void slot_free(Slot& s) {
+  slot_free_buffers(s);
   if (s.ev_pan) (void)hipEventDestroy(s.ev_pan);
   if (s.ev_la) (void)hipEventDestroy(s.ev_la);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -224,7 +243,7 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nt), dim3(256), lds, st, g);
+  hipLaunchKernelGGL(kern, dim3(nt, std::max(1, g.batch)), dim3(256), lds, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
@@ -237,14 +256,14 @@ int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
     HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(syrk128_kernel, dim3(nt), dim3(256), SY_LDS_BYTES, st, g);
+  hipLaunchKernelGGL(syrk128_kernel, dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
 
 // C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
 int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
-  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
+  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower) * std::max(1, g.batch);
   if (nt <= 0) return SIGP_OK;
   if (nt >= h->opt_small_tiles) return h->opt_syrk_v2 ? launch_syrk128(h, st, g) : launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
   g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
@@ -252,38 +271,47 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */)
 }
 
 // ---- builds -----------------------------------------------------------------------------------------
-void make_kparams(sigp_handle* h, int kernel_id, double ell, double sn) {
-  h->kp.kernel_id = kernel_id;
-  h->kp.c_rbf = -0.5 / (ell * ell);
-  h->kp.inv_ell = 1.0 / ell;
-  h->kp.sn = sn;
+KParams make_kparams(int kernel_id, double ell, double sn, int ds) {
+  KParams kp;
+  kp.kernel_id = kernel_id; kp.ds = ds;
+  kp.c_rbf = -0.5 / (ell * ell);
+  kp.inv_ell = 1.0 / ell;
+  kp.sn = sn;
+  return kp;
 }
 
-// RBF / Matern build of K~ (lower) + ride rows into slot s from device X, y, Xs
-int build_cov(sigp_handle* h, Slot& s, const double* X, const double* y, const double* Xs, long n, long d, long dp,
-              long n_pad, long m, const KParams& kp) {
-  const long ld = n_pad;
-  {
-    ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, (double)n * n / 2 * (3.0 * d + 20), 8.0 * n * d + 4.0 * n * (n + 1));
-    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T));
-    hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, (int)dp, (int)d, (int)n, s.mat, ld, kp);
-    HIPCHK(h, hipGetLastError());
-    dim3 g2((unsigned)(n_pad / 256 + (n_pad % 256 ? 1 : 0)), RIDE);
-    hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, s.s_upd, X, Xs, y, (int)dp, (int)d, (int)n, (int)n_pad, (int)m,
-                       1, s.mat + n_pad * ld, ld, kp, 1);
-    HIPCHK(h, hipGetLastError());
-  }
+// push the first nb entries of s.kps_host to the device (stream-ordered; kps_host stays untouched until retire)
+int upload_kparams(sigp_handle* h, Slot& s, int nb) {
+  HIPCHK(h, hipMemcpyAsync(s.kps, s.kps_host, (size_t)nb * sizeof(KParams), hipMemcpyHostToDevice, s.s_upd));
   return SIGP_OK;
 }
 
-// ---- blocked Cholesky on slot s (augmented with the ride rows) --------------------------------------
-int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
+// RBF / Matern build of K~ (lower) + ride rows for the nb lockstep members of slot s.  Member b uses data set
+// kps[b].ds: X + ds*strideX, y + ds*stridey, Xs + ds*strideXs.
+int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, const double* y, long stridey, const double* Xs,
+              long strideXs, long n, long d, long dp, long n_pad, long m) {
+  const long ld = n_pad;
+  ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
+  dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), (unsigned)nb);
+  hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps);
+  HIPCHK(h, hipGetLastError());
+  dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
+  hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, s.s_upd, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
+                     (int)n_pad, (int)m, 1, s.mat + n_pad * ld, s.matStride, ld, s.kps, 1);
+  HIPCHK(h, hipGetLastError());
+  return SIGP_OK;
+}
+
+// ---- blocked Cholesky of the nb lockstep members of slot s (each augmented with its ride rows) --------
+// Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
+// GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
+int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
   const int W = std::max(1, h->opt_outer);
   double* M = s.mat;
-  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
+  HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
   static bool diag_attr = false;
   if (!diag_attr) {
     HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
@@ -297,29 +325,29 @@ int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
     HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
   }
 
-  // lower-trapezoid update  C[cols ccol0..ccol1, rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
+  // lower-trapezoid update  C[cols ccol0.., rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
   auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1) -> int {
     const long o = (long)ccol0 * NB;
     GemmArgs g{};
     g.A = M + o * ld + (long)kcol0 * NB; g.lda = ld;
     g.B = g.A; g.ldb = ld;
     g.C = M + o * ld + o; g.ldc = ld;
+    g.batch = nb; g.sA = g.sB = g.sC = s.matStride;
     g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
-    const double nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1);
+    const double nt = (double)gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1) * nb;
     if (nt <= 0) return SIGP_OK;
     ProfScope ps(h, st, kclass, nt * 2.0 * NB * NB * g.K, nt * 2.0 * NB * NB * 8);
     return gemm_sub_auto(h, st, g);
   };
   // factor block columns [J0, J0+Wp) (already up to date) by binary recursion: the left half, a rank-(half) update
-  // of the right half's columns, then the right half.  Every update inside a panel of width Wp has K >= 128 and
-  // touches only that panel's columns, so most of the panel-internal flops also run at large K.
+  // of the right half's columns, then the right half.
   std::function<int(int, int)> panel = [&](int J0, int Wp) -> int {
     if (Wp == 1) {
       const int c = J0;
       {
-        ProfScope ps(h, sp, SIGP_KC_DIAG, 2.0 * NB * NB * NB / 3, 3.0 * NB * NB * 8);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
-                           s.dinv + (long)c * NB * NB, s.info, c * NB, 0);
+        ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3, nb * 3.0 * NB * NB * 8);
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
+                           s.dinv + (long)c * NB * NB, s.info, c * NB, 0, s.matStride, s.dinvStride);
         HIPCHK(h, hipGetLastError());
       }
       const long o = (long)(c + 1) * NB;
@@ -328,8 +356,9 @@ int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
       g.A = M + o * ld + (long)c * NB; g.lda = ld;
       g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
       g.C = M + o * ld + (long)c * NB; g.ldc = ld;
+      g.batch = nb; g.sA = g.sC = s.matStride; g.sB = s.dinvStride;
       g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
-      ProfScope ps(h, sp, SIGP_KC_TRSM, 2.0 * rows_below * NB * NB * NB, 2.0 * rows_below * NB * NB * 8);
+      ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
       return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
     }
     const int hw = Wp / 2;
@@ -374,18 +403,18 @@ int potrf_slot(sigp_handle* h, Slot& s, long n_pad) {
   return SIGP_OK;
 }
 
-// epilogue reductions on the ride block of slot s + async copy of results / info to pinned host memory
-int epilogue_slot(sigp_handle* h, Slot& s, long n, long n_pad, long m) {
+// epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
+int epilogue_slot(sigp_handle* h, Slot& s, int nb, long n, long n_pad, long m) {
   const long ld = n_pad;
   double* Z = s.mat + n_pad * ld;
   {
-    ProfScope ps(h, s.s_upd, SIGP_KC_EPILOGUE, 4.0 * (m + 1) * n, 8.0 * (m + 2) * n);
-    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(m + 2)), dim3(256), 0, s.s_upd, Z, ld, Z, s.mat, ld, (int)n, (int)n_pad,
-                       (int)(m + 1), s.res);
+    ProfScope ps(h, s.s_upd, SIGP_KC_EPILOGUE, nb * 4.0 * (m + 1) * n, nb * 8.0 * (m + 2) * n);
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(m + 2), (unsigned)nb), dim3(256), 0, s.s_upd, Z, ld, Z, s.mat, ld, (int)n,
+                       (int)n_pad, (int)(m + 1), s.res, s.matStride, s.matStride, s.matStride);
     HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, s.s_upd));
-  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, (size_t)nb * 512 * sizeof(double), hipMemcpyDeviceToHost, s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, (size_t)nb * sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
   return SIGP_OK;
 }
 
@@ -471,6 +500,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "group")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
   if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value > 64) return SIGP_BAD_ARG;
@@ -500,7 +530,7 @@ int sigp_set_train(sigp_handle* h, const double* X, int64_t n, int64_t d, int64_
   if ((rc = ensure(h, &h->y, &h->cap_y, n_pad))) return rc;
   if ((rc = ensure(h, &h->Xs, &h->cap_Xs, (long)RIDE * dp))) return rc;
   if ((rc = ensure(h, &h->stage, &h->cap_stage, std::max<long>(n * ldx, n_pad)))) return rc;
-  if ((rc = slot_reserve(h, h->slots[0], n_pad))) return rc;
+  if ((rc = slot_reserve(h, h->slots[0], n_pad, 1))) return rc;
   hipStream_t st = h->slots[0].s_upd;
   HIPCHK(h, hipMemcpyAsync(h->stage, X, (size_t)((n - 1) * ldx + d) * sizeof(double), hipMemcpyHostToDevice, st));
   {
@@ -546,10 +576,14 @@ int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde
   if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "kernel_build: kernel_id must be RBF or MATERN52 (use kernel_build_from_sigma for the reference kernel)");
   if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "kernel_build: ell > 0 and sn_tilde >= 0 required");
   HIPCHK(h, hipSetDevice(h->device));
-  make_kparams(h, kernel_id, ell, sn_tilde);
+  h->kp = make_kparams(kernel_id, ell, sn_tilde, 0);
   h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
   h->kss_unit.assign((size_t)h->m, 1.0);
-  int rc = build_cov(h, h->slots[0], h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, h->kp);
+  int rc = slot_reserve(h, h->slots[0], h->n_pad, 1);
+  if (rc) return rc;
+  h->slots[0].kps_host[0] = h->kp;
+  if ((rc = upload_kparams(h, h->slots[0], 1))) return rc;
+  rc = build_cov(h, h->slots[0], 1, h->X, 0, h->y, 0, h->Xs, 0, h->n, h->d, h->dp, h->n_pad, h->m);
   if (rc) return rc;
   rc = sync_slot(h, h->slots[0]);
   if (rc) return rc;
@@ -602,9 +636,10 @@ static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t l
     g.A = h->XsA; g.lda = dp; g.B = h->T; g.ldb = dp; g.C = s.mat + n_pad * ld; g.ldc = ld; g.K = (int)dp;
     g.r0 = 0; g.r1 = RIDE / 64; g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
     if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
-    KParams kp = h->kp;
-    hipLaunchKernelGGL(ride_build_kernel, dim3((unsigned)((n_pad + 255) / 256), 1), dim3(256), 0, st, h->X, h->Xs, h->y, (int)dp, (int)h->d,
-                       (int)n, (int)n_pad, (int)h->m, 1, s.mat + n_pad * ld, ld, kp, 0);
+    s.kps_host[0] = h->kp;
+    if ((rc = upload_kparams(h, s, 1))) return rc;
+    hipLaunchKernelGGL(ride_build_kernel, dim3((unsigned)((n_pad + 255) / 256), 1, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
+                       (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, s.mat + n_pad * ld, 0L, ld, s.kps, 0);
     HIPCHK(h, hipGetLastError());
   }
   return SIGP_OK;
@@ -614,7 +649,7 @@ int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ld
   if (!h || h->n == 0 || !Sigma || ldsigma < h->d) return fail(h, SIGP_BAD_ARG, "kernel_build_from_sigma: bad argument");
   if (!(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "sn_tilde >= 0 required");
   HIPCHK(h, hipSetDevice(h->device));
-  make_kparams(h, SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde);
+  h->kp = make_kparams(SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde, 0);
   h->kernel_id = SIGP_KERNEL_NETDIFFUSION; h->ell = 0; h->sn_tilde = sn_tilde;
   // k~** = xs Sigma~ xs^T on the host (m x N x N flops, tiny): needs the host copies -> recompute from device Xs
   int rc = build_from_sigma_async(h, Sigma, ldsigma, sn_tilde);
@@ -644,7 +679,7 @@ int sigp_potrf(sigp_handle* h, int64_t* info) {
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "potrf: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = potrf_slot(h, s, h->n_pad);
+  int rc = potrf_slot(h, s, 1, h->n_pad);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
   rc = sync_slot(h, s);
@@ -660,7 +695,7 @@ int sigp_fit(sigp_handle* h, double* sigma_f, double* nlml) {
   if (!h || !h->factored) return fail(h, SIGP_BAD_ARG, "fit: call potrf first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = epilogue_slot(h, s, h->n, h->n_pad, h->m);
+  int rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m);
   if (rc) return rc;
   rc = sync_slot(h, s);
   if (rc) return rc;
@@ -693,14 +728,17 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
   } else {
     if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "bad kernel_id");
     if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "ell > 0 and sn_tilde >= 0 required");
-    make_kparams(h, kernel_id, ell, sn_tilde);
+    h->kp = make_kparams(kernel_id, ell, sn_tilde, 0);
     h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
     h->kss_unit.assign((size_t)h->m, 1.0);
-    rc = build_cov(h, s, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, h->kp);
+    if ((rc = slot_reserve(h, s, h->n_pad, 1))) return rc;
+    s.kps_host[0] = h->kp;
+    if ((rc = upload_kparams(h, s, 1))) return rc;
+    rc = build_cov(h, s, 1, h->X, 0, h->y, 0, h->Xs, 0, h->n, h->d, h->dp, h->n_pad, h->m);
     if (rc) return rc;
   }
-  if ((rc = potrf_slot(h, s, h->n_pad))) return rc;
-  if ((rc = epilogue_slot(h, s, h->n, h->n_pad, h->m))) return rc;
+  if ((rc = potrf_slot(h, s, 1, h->n_pad))) return rc;
+  if ((rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m))) return rc;
   if ((rc = sync_slot(h, s))) return rc;
   const int info = *s.info_host;
   h->fit_res.assign(s.res_host, s.res_host + 512);
@@ -821,13 +859,15 @@ int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, doub
       }
     } else {
       dim3 g2((unsigned)((n_pad + 255) / 256), RIDE);
-      hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, st, h->X, xs_dev, (const double*)nullptr, (int)dp, (int)h->d, (int)n,
-                         (int)n_pad, (int)mc, 0, h->scratchZ, ld, h->kp, 1);
+      s.kps_host[0] = h->kp;
+      if ((rc = upload_kparams(h, s, 1))) return rc;
+      hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, st, h->X, 0L, xs_dev, 0L, (const double*)nullptr, 0L, (int)dp, (int)h->d, (int)n,
+                         (int)n_pad, (int)mc, 0, h->scratchZ, 0L, ld, s.kps, 1);
       HIPCHK(h, hipGetLastError());
     }
     if ((rc = solve_rows_forward(h, s, h->scratchZ, n_pad))) return rc;
-    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(mc + 1)), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
-                       (int)n_pad, (int)mc, s.res);
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(mc + 1), 1), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
+                       (int)n_pad, (int)mc, s.res, 0L, 0L, 0L);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -897,44 +937,55 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
   if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..16");
   HIPCHK(h, hipSetDevice(h->device));
   const long n = h->b_n, d = h->b_d, dp = h->b_dp, m = h->b_m, n_pad = h->b_npad;
+  // fits are factorised in lockstep groups of G (one launch covers the same step of G fits); `concurrency`
+  // groups are in flight on separate stream pairs so one group's panel chain overlaps another's updates
+  const int G = (int)std::max<long>(1, std::min<long>(h->opt_group, count));
+  const long ngroups = (count + G - 1) / G;
+  const int nslots = (int)std::min<long>(concurrency, ngroups);
   int rc;
-  for (int k = 0; k < concurrency; ++k)
-    if ((rc = slot_reserve(h, h->slots[k], n_pad))) return rc;
-  h->nslots = std::max(h->nslots, concurrency);
+  for (int k = 0; k < nslots; ++k)
+    if ((rc = slot_reserve(h, h->slots[k], n_pad, G))) return rc;
+  h->nslots = std::max(h->nslots, nslots);
+  for (long i = 0; i < count; ++i)
+    if (!(ell[i] > 0) || !(sn_tilde[i] >= 0)) return fail(h, SIGP_BAD_ARG, "batch_run: ell > 0 and sn_tilde >= 0 required");
   std::vector<double> kss((size_t)std::max<long>(m, 1), 1.0);
-  std::vector<long> inflight((size_t)concurrency, -1);
-  std::vector<double> snv((size_t)concurrency, 0.0);
+  std::vector<long> inflight((size_t)nslots, -1);   // group index running on each slot
   auto retire = [&](int k) -> int {
     Slot& s = h->slots[k];
     HIPCHK(h, hipStreamSynchronize(s.s_upd));
-    const long i = inflight[k];
-    finish_results(s.res_host, *s.info_host, n, m, snv[k], kss.data(), out + 4 * i, mean ? mean + i * m : nullptr,
-                   var ? var + i * m : nullptr);
+    const long g0 = inflight[k] * G;
+    const int nb = (int)std::min<long>(G, count - g0);
+    for (int b = 0; b < nb; ++b) {
+      const long i = g0 + b;
+      finish_results(s.res_host + 512 * b, s.info_host[b], n, m, sn_tilde[i], kss.data(), out + 4 * i, mean ? mean + i * m : nullptr,
+                     var ? var + i * m : nullptr);
+    }
     inflight[k] = -1;
     return SIGP_OK;
   };
   double enq_ms = 0, wait_ms = 0;
-  for (long i = 0; i < count; ++i) {
-    const int k = (int)(i % concurrency);
+  for (long g = 0; g < ngroups; ++g) {
+    const int k = (int)(g % nslots);
     auto tw0 = std::chrono::steady_clock::now();
     if (inflight[k] >= 0 && (rc = retire(k))) return rc;
     auto tw1 = std::chrono::steady_clock::now();
     wait_ms += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
     Slot& s = h->slots[k];
-    const long b = (first + i) % h->b_count;
-    KParams kp;
-    kp.kernel_id = kernel_id; kp.c_rbf = -0.5 / (ell[i] * ell[i]); kp.inv_ell = 1.0 / ell[i]; kp.sn = sn_tilde[i];
-    if (!(ell[i] > 0) || !(sn_tilde[i] >= 0)) return fail(h, SIGP_BAD_ARG, "batch_run: ell > 0 and sn_tilde >= 0 required");
-    if ((rc = build_cov(h, s, h->bX + b * n_pad * dp, h->by + b * n_pad, h->bXs + b * RIDE * dp, n, d, dp, n_pad, m, kp))) return rc;
-    if ((rc = potrf_slot(h, s, n_pad))) return rc;
-    if ((rc = epilogue_slot(h, s, n, n_pad, m))) return rc;
-    inflight[k] = i; snv[k] = sn_tilde[i];
+    const long g0 = g * G;
+    const int nb = (int)std::min<long>(G, count - g0);
+    for (int b = 0; b < nb; ++b) s.kps_host[b] = make_kparams(kernel_id, ell[g0 + b], sn_tilde[g0 + b], (int)((first + g0 + b) % h->b_count));
+    if ((rc = upload_kparams(h, s, nb))) return rc;
+    if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m))) return rc;
+    if ((rc = potrf_slot(h, s, nb, n_pad))) return rc;
+    if ((rc = epilogue_slot(h, s, nb, n, n_pad, m))) return rc;
+    inflight[k] = g;
     enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
   }
-  if (h->opt_host_timing)
-    fprintf(stderr, "[sigp] batch_run: %ld fits, host enqueue %.3f ms/fit, host wait-on-retire %.3f ms/fit\n", (long)count, enq_ms / count, wait_ms / count);
-  for (int k = 0; k < concurrency; ++k)
+  for (int k = 0; k < nslots; ++k)
     if (inflight[k] >= 0 && (rc = retire(k))) return rc;
+  if (h->opt_host_timing)
+    fprintf(stderr, "[sigp] batch_run: %ld fits in %ld groups of %d, host enqueue %.3f ms/fit, host wait-on-retire %.3f ms/fit\n", (long)count,
+            ngroups, G, enq_ms / count, wait_ms / count);
   // slot 0 no longer holds the single-fit state
   h->built = h->factored = h->fitted = false;
   return SIGP_OK;
@@ -1041,7 +1092,7 @@ int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps,
   for (int r = 0; r < reps + 2; ++r) {
     HIPCHK(h, hipMemcpyAsync(a1, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip);
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip, 0L, 0L);
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
@@ -1076,7 +1127,7 @@ int sigp_debug_mfma_peak(sigp_handle* h, int blocks, int iters, double* tflops, 
 }
 
 // time the lower-tile update C -= P P^T (128x128 tiles) on a synthetic (rt*128) x K panel, tile walk `patch`
-int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg) {
+int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
   if (!h || rt < 1 || K < 16 || reps < 1) return SIGP_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const long n = (long)rt * NB, ldp = K, ldc = n;
@@ -1090,6 +1141,9 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
   hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
   GemmArgs g{};
   g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp; g.C = Cm; g.ldc = ldc; g.K = K; g.r0 = 0; g.r1 = rt; g.c0 = 0; g.c1 = rt; g.lower = 1; g.patch = patch; g.dbg = dbg;
+  unsigned long long* stamp = nullptr;
+  const int ngrid = gemm_grid_size(0, rt, 0, rt, 1, patch);
+  if (clock_ghz && small == 2) { HIPCHK(h, hipMalloc((void**)&stamp, (size_t)ngrid * 16)); HIPCHK(h, hipMemset(stamp, 0, (size_t)ngrid * 16)); g.stamp = stamp; }
   if (small == 1) { g.r1 *= 2; g.c1 *= 2; }
   double tot = 0;
   for (int r = 0; r < reps + 2; ++r) {
@@ -1100,6 +1154,14 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
     HIPCHK(h, hipStreamSynchronize(st));
     float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     if (r >= 2) tot += ms;
+  }
+  if (stamp) {
+    std::vector<unsigned long long> hs((size_t)ngrid * 2);
+    HIPCHK(h, hipMemcpy(hs.data(), stamp, hs.size() * 8, hipMemcpyDeviceToHost));
+    double sc = 0, sr = 0;
+    for (int i = 0; i < ngrid; ++i) { sc += (double)hs[2 * i]; sr += (double)hs[2 * i + 1]; }
+    *clock_ghz = sr > 0 ? sc / (sr * 10.0) : 0.0;   // s_memrealtime ticks at 100 MHz
+    (void)hipFree(stamp);
   }
   const double nt = (double)rt * (rt + 1) / 2;
   if (ms_avg) *ms_avg = tot / reps;

@@ -33,10 +33,13 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
 
   int bi, bj;
   if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
-  const double* Ag = g.A + (long)bi * SY_T * g.lda;
-  const double* Bg = g.B + (long)bj * SY_T * g.ldb;
-  double* Cg = g.C + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
+  const long bz = blockIdx.y;
+  const double* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
+  const double* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
+  double* Cg = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
 
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   d4 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -67,36 +70,54 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
   const int fo0 = ((lq ^ x) & 7) * 2, fo1 = (((4 + lq) ^ x) & 7) * 2;
   const int arow0 = (wm * 64 + lr) * KT, brow0 = (wn * 64 + lr) * KT;
 
+  // Software pipeline (2 LDS buffers, one barrier per K-slice, placed MID-slice):
+  //   read group-1 fragments of slice s | MFMA group 0 | barrier (slice s+1 landed, slice s fully read)
+  //   | DMA slice s+2 into the buffer just freed, read group-0 fragments of slice s+1 | MFMA group 1
+  // so every fragment read and every DMA has a 32-MFMA group (2048 cycles) to land behind.
   const int nst = g.K / KT;
+  d2 a0[4], b0[4], a1[4], b1[4];
   SY_ISSUE(0, 0);
   __syncthreads();
+  if (nst > 1) SY_ISSUE(KT, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a0[i] = *(const d2*)(As + arow0 + i * 16 * KT + fo0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b0[j] = *(const d2*)(Bs + brow0 + j * 16 * KT + fo0);
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst) SY_ISSUE((s + 1) * KT, buf ^ 1);
     const double* Ab = As + buf * SY_T * KT + arow0;
     const double* Bb = Bs + buf * SY_T * KT + brow0;
-    d2 a0[4], b0[4], a1[4], b1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a0[i] = *(const d2*)(Ab + i * 16 * KT + fo0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b0[j] = *(const d2*)(Bb + j * 16 * KT + fo0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) a1[i] = *(const d2*)(Ab + i * 16 * KT + fo1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = *(const d2*)(Bb + j * 16 * KT + fo1);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[i][e], b0[j][e], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nst && !(g.dbg & 1)) SY_ISSUE((s + 2) * KT, buf);
+    if (s + 1 < nst) {
+      const double* An = As + (buf ^ 1) * SY_T * KT + arow0;
+      const double* Bn = Bs + (buf ^ 1) * SY_T * KT + brow0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = *(const d2*)(An + i * 16 * KT + fo0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b0[j] = *(const d2*)(Bn + j * 16 * KT + fo0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[i][e], b1[j][e], acc[i][j], 0, 0, 0);
-    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
 #undef SY_ISSUE
 
@@ -106,6 +127,10 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr] = -acc[i][j][r];
+  if (g.stamp && tid == 0) {
+    g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
+    g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
 }
 
 }  // namespace sigp

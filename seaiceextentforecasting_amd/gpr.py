@@ -217,7 +217,7 @@ class GPR:
         return out
 
     # ---- batches (retro loop :176-248, grid :210-211) ------------------------------------------
-    def fit_batch(self, X, y, Xs, ell, sn_tilde, concurrency=2):
+    def fit_batch(self, X, y, Xs, ell, sn_tilde, concurrency=2, group=8):
         """Independent fits sharing (n, d, m).  X [B,n,d] (or [n,d] shared), y [B,n] (or [n]), Xs [B,m,d]
         (or [m,d] / None), ell [F], sn_tilde [F]; F fits, fit i uses data set i % B.  RBF / Matern only.
         Returns dict(sigma_f, nlml, info, sigma_n, mean [F,m], var [F,m])."""
@@ -243,10 +243,12 @@ class GPR:
             raise ValueError("ell and sn_tilde must have the same length")
         self._check(self._lib.sigp_batch_upload(self._h, B, L.ptr(Xb), n * d, L.ptr(yb), n, L.ptr(Xsb), m * d, n, d, m), "batch_upload")
         self._batch_m = m
-        return self.run_batch(0, F, ell, sn, concurrency)
+        return self.run_batch(0, F, ell, sn, concurrency, group)
 
-    def run_batch(self, first, count, ell, sn_tilde, concurrency=2):
-        """Run ``count`` fits on the data sets already resident in HBM (after fit_batch / upload)."""
+    def run_batch(self, first, count, ell, sn_tilde, concurrency=2, group=8):
+        """Run ``count`` fits on the data sets already resident in HBM (after fit_batch / upload).
+        ``group`` fits are factorised in lockstep by each launch; ``concurrency`` groups are in flight."""
+        self.set_option("group", group)
         ell = L.f64(np.atleast_1d(ell), 1)
         sn = L.f64(np.atleast_1d(sn_tilde), 1)
         out = np.zeros((count, 4))
@@ -262,13 +264,13 @@ class GPR:
         return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
                     mean=mean[:, :mdim], var=var[:, :mdim])
 
-    def nlml_grid(self, X, y, ells, sns, concurrency=2):
+    def nlml_grid(self, X, y, ells, sns, concurrency=2, group=8):
         """nlML on the (l, sn~) grid for one data set -- the offline 20x20 search implied by
         north/June1st.py:210-211.  Returns [len(ells), len(sns)], +inf where K~ is not SPD."""
         ells = np.asarray(ells, dtype=np.float64).reshape(-1)
         sns = np.asarray(sns, dtype=np.float64).reshape(-1)
         E, S = np.meshgrid(ells, sns, indexing="ij")
-        r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency)
+        r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency, group=group)
         return r["nlml"].reshape(len(ells), len(sns))
 
     # ---- measurement ---------------------------------------------------------------------------

@@ -33,7 +33,25 @@ def stage(n, d, kind, m=3, seed=1, outer=None, la=None):
              rel(mu, ref["fmean"]), rel(var, ref["fvar"]), rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]), rel(al, ref["alpha"])))
     gp.close()
 
+def batch_check(n=640, d=8, B=5, F=11, group=4, conc=2):
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 2, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 100 + b, m=2)
+    ell = np.sqrt(d) * np.logspace(-0.3, 0.3, F); sn = np.logspace(-3, -1, F)
+    gp = GPR(kernel="rbf")
+    r = gp.fit_batch(Xb, yb, Xsb, ell, sn, concurrency=conc, group=group)
+    worst = 0
+    for i in range(F):
+        b = i % B
+        ref = O.fit_predict(Xb[b], yb[b], Xsb[b], ell[i], sn[i], kind="rbf", ref_idiom=False)
+        worst = max(worst, rel(r["mean"][i], ref["fmean"]), rel(r["var"][i], ref["fvar"]), rel(r["nlml"][i], ref["nlml"]), rel(r["sigma_f"][i], ref["sigma_f"]))
+    print("batch n=%d B=%d F=%d group=%d conc=%d: worst rel err %.2e  info %s" % (n, B, F, group, conc, worst, r["info"].tolist()))
+    gp.close()
+
 if __name__ == "__main__":
+    if "--batch" in sys.argv:
+        batch_check(); batch_check(group=1, conc=3); batch_check(n=300, B=3, F=20, group=8, conc=2); batch_check(group=16, conc=1)
+        sys.exit(0)
     for n in (1, 7, 64, 128, 129, 257, 640):
         for kind in ("rbf", "matern52", "netdiffusion"):
             if kind == "netdiffusion" and n < 7: continue

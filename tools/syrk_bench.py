@@ -4,24 +4,24 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seaiceextentforecasting_amd import _lib as L
 lib = L.load()
 lib.sigp_debug_time_syrk.restype = C.c_int
-lib.sigp_debug_time_syrk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, L._dp, L._dp, C.c_int]
+lib.sigp_debug_time_syrk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, L._dp, L._dp, C.c_int, L._dp]
 lib.sigp_debug_mfma_peak.restype = C.c_int
 lib.sigp_debug_mfma_peak.argtypes = [C.c_void_p, C.c_int, C.c_int, L._dp, C.c_double]
 h = C.c_void_p(); assert lib.sigp_create(C.byref(h), 0, 0) == 0
 lib.sigp_set_option(h, b"reserve_cus", 0)
-ms, tf = C.c_double(), C.c_double()
+ms, tf, ghz = C.c_double(), C.c_double(), C.c_double()
 for seed in (0.25, -1.0):
     lib.sigp_debug_mfma_peak(h, 512, 20000, C.byref(tf), seed)
     print("mfma rate probe, %s operands: %.1f TFLOP/s" % ("constant" if seed > 0 else "random", tf.value))
 mode = sys.argv[1] if len(sys.argv) > 1 else "ablate"
 if mode == "ablate":
     print("rt   K small dbg |    ms   TFLOP/s")
-    for rt, K in ((62, 256), (62, 512), (32, 256), (16, 256)):
-        for small in (0, 2):
-            for dbg in ((0,) if small == 2 else (0, 7)):
-                lib.sigp_debug_time_syrk(h, rt, K, 0, small, 5, C.byref(ms), C.byref(tf), dbg)
-                print("%2d %4d %5d %3d | %6.3f  %6.1f" % (rt, K, small, dbg, ms.value, tf.value))
+    for rt, K in ((62, 256), (62, 512), (62, 1024), (62, 2048), (32, 512)):
+        for small in (2,):
+            for dbg in (0, 1):
+                lib.sigp_debug_time_syrk(h, rt, K, 0, small, 5, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
+                print("%2d %4d %5d %3d | %6.3f  %6.1f   in-kernel clock %.2f GHz" % (rt, K, small, dbg, ms.value, tf.value, ghz.value))
 else:
     rt, K, small = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    lib.sigp_debug_time_syrk(h, rt, K, 0, small, 3, C.byref(ms), C.byref(tf), 0)
+    lib.sigp_debug_time_syrk(h, rt, K, 0, small, 3, C.byref(ms), C.byref(tf), 0, None)
     print("%2d %4d %5d | %6.3f  %6.1f" % (rt, K, small, ms.value, tf.value))
