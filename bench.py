@@ -17,6 +17,7 @@ import time
 
 import numpy as np
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per HIP stream (panel / update streams overlap)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -33,14 +34,14 @@ def grid_point(i, d):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--years", type=int, default=8, help="distinct synthetic data sets resident per rank")
-    ap.add_argument("--concurrency", type=int, default=2, help="lockstep groups in flight")
-    ap.add_argument("--group", type=int, default=8, help="fits factorised in lockstep per launch")
-    ap.add_argument("--outer", type=int, default=None)
+    ap.add_argument("--concurrency", type=int, default=1, help="lockstep groups in flight")
+    ap.add_argument("--group", type=int, default=16, help="fits factorised in lockstep per launch")
+    ap.add_argument("--outer", type=int, default=8, help="outer panel width in 128-column blocks (K of the trailing update = 128*outer)")
     ap.add_argument("--reserve-cus", type=int, default=None)
     ap.add_argument("--host-timing", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")

@@ -61,6 +61,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise SigpError("libsigp.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `make -C seaiceextentforecasting_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # must precede HIP runtime initialisation to take effect
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

@@ -43,7 +43,7 @@ def pearson_rp(y, A):
     r = (Am @ ym) / (np.linalg.norm(Am, axis=1) * np.linalg.norm(ym))
     r = np.clip(r, -1.0, 1.0)
     ab = n / 2.0 - 1.0
-    p = 2.0 * special.btdtr(ab, ab, 0.5 * (1.0 - np.abs(r)))
+    p = 2.0 * special.betainc(ab, ab, 0.5 * (1.0 - np.abs(r)))   # = 2*BetaCDF, what scipy.stats.pearsonr evaluates
     return r, p
 
 
@@ -81,12 +81,16 @@ def design_matrix(feats, standardise):
 
 
 def laplacian_M(X):
-    """Negative graph Laplacian of |cov(X)| (north/June1st.py:231-233)."""
-    X = np.asarray(X, dtype=np.float64)
-    Xc = X - X.mean(0)
-    M = np.abs(Xc.T @ Xc / X.shape[0])
+    """Negative graph Laplacian of |cov(X)| (north/June1st.py:231-233).
+
+    Uses ``np.cov`` itself, not an algebraically equal formula: for the reference's extreme length scales
+    (July region 3, l = 3.1e10) ``expm(l*M)`` amplifies a 1-ulp difference in M to ~1e-6 in
+    the forecast, so M has to be bit-identical to the reference's."""
+    # the reference's X is a transposed (Fortran-ordered) view (SURVEY App. C-8); np.cov's BLAS call, and hence its
+    # rounding, depends on that layout -- 63/63 golden records are bit-identical in F order, 0/63 in C order
+    M = np.atleast_2d(np.abs(np.cov(np.asfortranarray(X, dtype=np.float64), rowvar=False, bias=True)))
     np.fill_diagonal(M, 0.0)
-    np.fill_diagonal(M, -M.sum(0))
+    np.fill_diagonal(M, -np.sum(M, axis=0))
     return M
 
 

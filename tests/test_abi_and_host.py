@@ -1,0 +1,148 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/sigp.h declares (no compute calls),
+the product path fails loudly without a GPU, and the host logic (feature rules, tables, sharding)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from seaiceextentforecasting_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "seaiceextentforecasting_amd", "csrc")])
+    return _lib
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    hdr = open(os.path.join(ROOT, "include", "sigp.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sigp_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    L = lib.load()
+    for name in declared:
+        assert hasattr(L, name), "libsigp.so does not export %s" % name
+    assert declared == set(lib.SIGNATURES), "ctypes table and header disagree: %s" % (declared ^ set(lib.SIGNATURES))
+    assert L.sigp_version() >= 100
+
+
+def test_product_path_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from seaiceextentforecasting_amd import GPR
+    with pytest.raises(lib.SigpError):
+        GPR(kernel="rbf")
+
+
+def test_product_package_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "seaiceextentforecasting_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no CPU fallback", ""), fn
+
+
+def test_feature_rules_match_the_oracle(golden):
+    """features.select_features / design_matrix / laplacian_M (vectorised) pick exactly what the reference did."""
+    import seaiceextentforecasting_amd as S
+    g = golden
+    script = g["script"].replace("_retro", "")
+    tab = S.SCRIPT_TABLE[script]
+    otab = O.SCRIPT_TABLE[script]
+    assert np.allclose(tab["ell"], otab["ell"], rtol=0, atol=0) and np.allclose(tab["sn"], otab["sn"], rtol=0, atol=0)
+    for r in g["records"]:
+        k = int(r["k"])
+        if g["kind"] == "retro":
+            year = int(r["year"])
+            key = "anoms_%d" % (year - 1 if tab["drop_first"] else year)
+            sic, sst = g["SIC"][key], (g["SST"][key] if g["SST"] else None)
+        else:
+            sic, sst = g["SIC"]["anoms"], (g["SST"]["anoms"] if g["SST"] else None)
+        feats = S.select_features(r["y"], sic, sst, rule=tab["rule"], k=k, pthr=tab["pthr"])
+        X, Xs = S.design_matrix(feats, tab["standardise"])
+        assert X.shape == r["X"].shape
+        assert np.max(np.abs(X - r["X"])) <= 1e-13 * max(1.0, np.abs(r["X"]).max())
+        assert np.max(np.abs(Xs - r["Xs"])) <= 1e-13 * max(1.0, np.abs(r["Xs"]).max())
+        M = S.laplacian_M(X)
+        assert np.array_equal(S.laplacian_M(r["X"]), r["M"])      # bit-identical on the reference's own X
+        assert np.max(np.abs(M - r["M"])) <= 1e-12 * max(1.0, np.abs(r["M"]).max())
+        assert X.flags["C_CONTIGUOUS"]
+
+
+def test_pearson_vectorised_equals_scipy():
+    from scipy.stats import pearsonr
+    from seaiceextentforecasting_amd.features import pearson_rp
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal(37)
+    A = rng.standard_normal((20, 37)) + 0.3 * y
+    r, p = pearson_rp(y, A)
+    for i in range(20):
+        r0, p0 = pearsonr(y, A[i])
+        assert abs(r[i] - r0) <= 1e-14 and abs(p[i] - p0) <= 1e-12 * max(p0, 1e-300) + 1e-15
+
+
+def test_empty_feature_set_raises_like_the_reference():
+    import seaiceextentforecasting_amd as S
+    with pytest.raises(IndexError):
+        S.design_matrix([], False)
+
+
+def test_shard_indices_cover_everything_once():
+    import seaiceextentforecasting_amd as S
+    for n_items in (0, 1, 7, 40, 41):
+        for world in (1, 2, 3, 8):
+            allidx = np.concatenate([S.shard_indices(n_items, r, world) for r in range(world)])
+            assert sorted(allidx.tolist()) == list(range(n_items))
+    with pytest.raises(ValueError):
+        S.shard_indices(5, 3, 2)
+
+
+_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch.distributed as dist
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+B, n, d, F = 3, 40, 3, 7
+Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+for b in range(B):
+    Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 50 + b, m=1)
+ell = 1.0 + 0.1 * np.arange(F); sn = 0.05 + 0.01 * np.arange(F)
+def engine(Xl, yl, Xsl, e, s):          # CPU stand-in for GPR.fit_batch (the GPU engine is exercised by -m gpu)
+    out = dict(sigma_f=[], nlml=[], info=[], sigma_n=[], mean=[], var=[])
+    for i in range(len(e)):
+        r = O.fit_predict(Xl[i], yl[i], Xsl[i], e[i], s[i], kind="rbf", ref_idiom=False)
+        out["sigma_f"].append(r["sigma_f"]); out["nlml"].append(r["nlml"]); out["info"].append(0)
+        out["sigma_n"].append(r["sigma_n"]); out["mean"].append(r["fmean"]); out["var"].append(r["fvar"])
+    return {k: np.asarray(v) for k, v in out.items()}
+res = S.fit_batch_sharded(engine, Xb, yb, Xsb, ell, sn, rank, world, dist)
+for i in range(F):
+    r = O.fit_predict(Xb[i %% B], yb[i %% B], Xsb[i %% B], ell[i], sn[i], kind="rbf", ref_idiom=False)
+    assert abs(res["nlml"][i] - r["nlml"]) < 1e-12 and abs(res["mean"][i, 0] - r["fmean"][0]) < 1e-12, (rank, i)
+assert res["mean"].shape == (F, 1)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+'''
+
+
+def test_year_sharding_over_two_ranks_gloo(tmp_path):
+    """N>1 path: fits dealt round-robin over ranks, results all-gathered (world_size 2, gloo, CPU)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    port = 29500 + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists(), p.stdout[-2000:] + p.stderr[-2000:]
