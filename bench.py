@@ -121,7 +121,7 @@ def main():
         "whole_fit_frac_of_fp64_mfma_peak": value * flops_fit / 1e12 / world / PEAK_F64_MFMA_TFLOPS,
     }
     if rank == 0:
-        dom = prof["update_outer"]
+        dom = prof["syrk128"]
         if dom["launches"] and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
             out["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_kernel (outer trailing update, C -= A B^T)",
@@ -140,13 +140,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # reference-idiom CPU path (oracle, call-for-call north/June1st.py:264-277) on the host cores, one fit
         ncpu = os.cpu_count()
+        try:
+            from threadpoolctl import threadpool_info
+            ncpu = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [ncpu])
+        except Exception:
+            pass
         nb = n if n <= 8192 else 8192
         Xc, yc, Xsc = O.synthetic_problem(nb, d, 20240002, m=1)
         t0 = time.perf_counter()
         ref = O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=True)
         tc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
-                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True (NumPy %s / OpenBLAS, %d threads)" % (nb, d, np.__version__, ncpu),
+                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d)" % (nb, d, np.__version__, ncpu, os.cpu_count()),
                                "seconds": tc}
         if nb == n:   # parity of the timed configuration against the CPU path on the same inputs
             with GPR(kernel="rbf", device=local) as g2:

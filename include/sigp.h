@@ -36,9 +36,11 @@ enum { SIGP_F64 = 0, SIGP_F32 = 1 };
 enum { SIGP_KERNEL_NETDIFFUSION = 0, SIGP_KERNEL_RBF = 1, SIGP_KERNEL_MATERN52 = 2 };
 /* sigp_get_matrix selectors */
 enum { SIGP_MAT_K = 0, SIGP_MAT_L = 1 };
-/* kernel classes for sigp_profile_get */
-enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_INNER = 3,
-       SIGP_KC_UPDATE_OUTER = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_COUNT = 6 };
+/* kernel classes for sigp_profile_get (one per device kernel, so totals line up with rocprofv3 --stats):
+ * kbuild_kernel(+ride_build), potrf_diag_kernel, gemm_mfma_kernel<32,128> (panel solve),
+ * gemm_mfma_kernel<64,64> (updates with few tiles), syrk128_kernel (inner + trailing updates), epilogue_kernel */
+enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_SMALL = 3,
+       SIGP_KC_SYRK128 = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_COUNT = 6 };
 
 #define SIGP_MAX_RIDE 127 /* test points that can ride along one factorisation */
 

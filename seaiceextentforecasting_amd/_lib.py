@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libsigp.so")
 
 OK, NOT_SPD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
 KERNEL_IDS = {"netdiffusion": 0, "rbf": 1, "matern52": 2}
-KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_inner": 3, "update_outer": 4, "epilogue": 5}
+KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_small": 3, "syrk128": 4, "epilogue": 5}
 MAX_RIDE = 127
 
 _dp = C.POINTER(C.c_double)

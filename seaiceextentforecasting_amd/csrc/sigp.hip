@@ -263,9 +263,20 @@ int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
 
 // C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
 int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
-  const int nt = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower) * std::max(1, g.batch);
+  const int nb = std::max(1, g.batch);
+  const double nt1 = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
+  const int nt = (int)nt1 * nb;
   if (nt <= 0) return SIGP_OK;
-  if (nt >= h->opt_small_tiles) return h->opt_syrk_v2 ? launch_syrk128(h, st, g) : launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+  const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * 8;
+  if (nt >= h->opt_small_tiles && h->opt_syrk_v2) {
+    ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
+    return launch_syrk128(h, st, g);
+  }
+  if (nt >= h->opt_small_tiles) {
+    ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
+    return launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+  }
+  ProfScope ps(h, st, SIGP_KC_UPDATE_SMALL, flops, bytes);
   g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
   return launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
 }
@@ -334,9 +345,7 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
     g.C = M + o * ld + o; g.ldc = ld;
     g.batch = nb; g.sA = g.sB = g.sC = s.matStride;
     g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
-    const double nt = (double)gemm_tile_count(g.r0, g.r1, g.c0, g.c1, 1) * nb;
-    if (nt <= 0) return SIGP_OK;
-    ProfScope ps(h, st, kclass, nt * 2.0 * NB * NB * g.K, nt * 2.0 * NB * NB * 8);
+    (void)kclass;
     return gemm_sub_auto(h, st, g);
   };
   // factor block columns [J0, J0+Wp) (already up to date) by binary recursion: the left half, a rank-(half) update
@@ -364,11 +373,11 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
     const int hw = Wp / 2;
     int rc = panel(J0, hw);
     if (rc) return rc;
-    if ((rc = update(sp, SIGP_KC_UPDATE_INNER, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
+    if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
     return panel(J0 + hw, Wp - hw);
   };
   auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
-    return update(st, SIGP_KC_UPDATE_OUTER, J, Wc, J + Wc, c0, c1);
+    return update(st, SIGP_KC_SYRK128, J, Wc, J + Wc, c0, c1);
   };
 
   int rc = panel(0, std::min(W, T));
