@@ -39,7 +39,7 @@ SIGNATURES = {
     "sigp_batch_run": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
-    "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, _dp, _dp]),
+    "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, C.POINTER(C.c_double), _dp]),
     "sigp_profile": (C.c_int, [_h, C.c_int]),
     "sigp_profile_get": (C.c_int, [_h, C.c_int, _dp, C.POINTER(_i64), _dp, _dp]),
     "sigp_profile_reset": (C.c_int, [_h]),

@@ -7,7 +7,8 @@
 
 namespace sigp {
 
-enum { KID_NETDIFFUSION = 0, KID_RBF = 1, KID_MATERN52 = 2 };
+enum { KID_NETDIFFUSION = 0, KID_RBF = 1, KID_MATERN52 = 2,
+       KID_RBF_DLOGL = 17, KID_MATERN52_DLOGL = 18 };   // d k~ / d log(ell), for the exact MLII gradient
 
 struct KParams {
   int kernel_id;
@@ -19,7 +20,9 @@ struct KParams {
 
 __device__ inline double cov_from_sq(const KParams& kp, double sq) {
   if (kp.kernel_id == KID_RBF) return exp(kp.c_rbf * sq);
+  if (kp.kernel_id == KID_RBF_DLOGL) return exp(kp.c_rbf * sq) * sq * (kp.inv_ell * kp.inv_ell);   // k * |d|^2 / l^2
   const double s = sqrt(5.0 * sq) * kp.inv_ell;
+  if (kp.kernel_id == KID_MATERN52_DLOGL) return (s * s * (1.0 / 3.0)) * (1.0 + s) * exp(-s);
   return (1.0 + s + s * s * (1.0 / 3.0)) * exp(-s);
 }
 
@@ -31,9 +34,9 @@ constexpr int KB_DC = 32;   // feature chunk staged in LDS
 // blockIdx.z = batch member; its hyper-parameters and data set come from kps[z].
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      double* __restrict__ Mat, long strideM, long ld,
-                                                     const KParams* __restrict__ kps) {
+                                                     const KParams* __restrict__ kps, int full) {
   const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj > bi) return;
+  if (bj > bi && !full) return;   // full = 1: every tile, zero (not identity) on the padding (derivative matrices)
   const KParams kp = kps[blockIdx.z];
   X += kp.ds * strideX;
   Mat += blockIdx.z * strideM;
@@ -74,8 +77,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
     const int gi = bi * KB_T + rg + 8 * s, gj = bj * KB_T + c2;
     d2 v;
     if (gi >= n) {
-      v.x = (gi == gj) ? 1.0 : 0.0;
-      v.y = (gi == gj + 1) ? 1.0 : 0.0;
+      v.x = (gi == gj && !full) ? 1.0 : 0.0;
+      v.y = (gi == gj + 1 && !full) ? 1.0 : 0.0;
     } else {
       v.x = (gj < n) ? cov_from_sq(kp, acc[s][0]) + (gi == gj ? kp.sn : 0.0) : 0.0;
       v.y = (gj + 1 < n) ? cov_from_sq(kp, acc[s][1]) + (gi == gj + 1 ? kp.sn : 0.0) : 0.0;
@@ -185,6 +188,40 @@ __global__ void copy_block_kernel(const double* __restrict__ src, long lds, doub
   if (idx >= (long)rows * cols) return;
   const int r = (int)(idx / cols), c = (int)(idx % cols);
   dst[(long)r * ldd + c] = src[(long)r * lds + c];
+}
+
+// identity into a [n_pad][n_pad] buffer
+__global__ void set_identity_kernel(double* __restrict__ U, long ld, int n_pad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_pad * n_pad) return;
+  const int r = (int)(idx / n_pad), c = (int)(idx % n_pad);
+  U[(long)r * ld + c] = (r == c) ? 1.0 : 0.0;
+}
+
+// K13/K14 reductions (north/June1st.py:251-252).  Kneg = -K~^-1 (lower triangle valid), D = a symmetric
+// derivative matrix (full), a = A~ (K~^-1 y).  One block per row i < n:
+//   part[4i+0] = sum_j K~^-1_ij D_ij  (row i of the full symmetric product, from the lower triangle)
+//   part[4i+1] = a_i * sum_j D_ij a_j
+//   part[4i+2] = K~^-1_ii              part[4i+3] = a_i^2
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kneg, const double* __restrict__ D,
+                                                          const double* __restrict__ a, long ld, int n, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double t = 0.0, q = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const double dij = D[(long)i * ld + j];
+    const double kij = (j <= i) ? -Kneg[(long)i * ld + j] : -Kneg[(long)j * ld + i];
+    t += kij * dij;
+    q += dij * a[j];
+  }
+  t = block_reduce_sum(t, sh);
+  q = block_reduce_sum(q, sh);
+  if (threadIdx.x == 0) {
+    part[4 * i + 0] = t;
+    part[4 * i + 1] = a[i] * q;
+    part[4 * i + 2] = -Kneg[(long)i * ld + i];
+    part[4 * i + 3] = a[i] * a[i];
+  }
 }
 
 }  // namespace sigp

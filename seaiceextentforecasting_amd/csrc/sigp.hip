@@ -63,6 +63,10 @@ struct sigp_handle {
   double* Sig = nullptr; long cap_Sig = 0;    // Sigma~ padded [dp][dp]
   double* XsA = nullptr;                      // [128][dp] ride rows shifted by one (row 0 = 0) for the GEMM-form build
   double* stage = nullptr; long cap_stage = 0;// generic host->device staging
+  double* gU = nullptr; long cap_gU = 0;      // MLII gradient workspaces: L~^-T, -K~^-1, dK~  ([n_pad][n_pad] each)
+  double* gK = nullptr; long cap_gK = 0;
+  double* gD = nullptr; long cap_gD = 0;
+  double* gPart = nullptr; long cap_gPart = 0;
   std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
   std::vector<double> fit_res;                // epilogue reductions of the last fit (host copy)
   Slot slots[MAX_SLOTS];
@@ -304,7 +308,7 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
   const long ld = n_pad;
   ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
   dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), (unsigned)nb);
-  hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps);
+  hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
   hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, s.s_upd, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
@@ -480,7 +484,7 @@ int sigp_destroy(sigp_handle* h) {
   (void)hipDeviceSynchronize();
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
-  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs};
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart};
   for (double* p : bufs) if (p) (void)hipFree(p);
   delete h;
   return SIGP_OK;
@@ -760,7 +764,8 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
 }
 
 // ---- forward / backward block solves on a scratch ride block (predict for new points, alpha) --------
-static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
+static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad, int nchunks = 1) {
+  // nchunks > 1: Z holds nchunks*128 rows; all chunks advance in lockstep (grid.y = chunk)
   // Z[128][n_pad] <- Z L~^-T  : per block column kb: Z[:,kb] = Z[:,kb] inv(L_kk)^T ; Z[:,kb+1:] -= Z[:,kb] L[kb+1:,kb]^T
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);
@@ -769,10 +774,12 @@ static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
     GemmArgs g{};
     g.A = Z + (long)kb * NB; g.lda = ld; g.B = s.dinv + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
     g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    g.batch = nchunks; g.sA = g.sC = (long)RIDE * ld; g.sB = 0;
     int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, st, g);
     if (rc) return rc;
     if (kb + 1 < T) {
       GemmArgs u{};
+      u.batch = nchunks; u.sA = u.sC = (long)RIDE * ld; u.sB = 0;
       u.A = Z + (long)kb * NB; u.lda = ld;
       u.B = s.mat + (long)(kb + 1) * NB * ld + (long)kb * NB; u.ldb = ld;
       u.C = Z + (long)(kb + 1) * NB; u.ldc = ld;
@@ -1010,17 +1017,105 @@ int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X
   return sigp_batch_run(h, 0, batch, kernel_id, ell, sn_tilde, concurrency, out, mean, var);
 }
 
+// D <- X S X^T for a symmetric S [N][N] on the host (full symmetric result, zero on the padding)
+static int build_xsxt(sigp_handle* h, const double* S, int64_t lds, double* D) {
+  hipStream_t st = h->slots[0].s_upd;
+  const long N = h->d, dp = h->dp, n_pad = h->n_pad, ld = n_pad;
+  int rc;
+  if ((rc = ensure(h, &h->Sig, &h->cap_Sig, dp * dp))) return rc;
+  if ((rc = ensure(h, &h->T, &h->cap_T, n_pad * dp))) return rc;
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, N * lds))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->stage, S, (size_t)((N - 1) * lds + N) * sizeof(double), hipMemcpyHostToDevice, st));
+  const long tot = dp * dp;
+  hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)lds, (int)N, (int)N, h->Sig, (int)dp, (int)dp);
+  HIPCHK(h, hipGetLastError());
+  GemmArgs g{};
+  g.A = h->X; g.lda = dp; g.B = h->Sig; g.ldb = dp; g.C = h->T; g.ldc = dp; g.K = (int)dp;
+  g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(dp / 64); g.lower = 0;
+  if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+  GemmArgs g2{};
+  g2.A = h->T; g2.lda = dp; g2.B = h->X; g2.ldb = dp; g2.C = D; g2.ldc = ld; g2.K = (int)dp;
+  g2.r0 = 0; g2.r1 = (int)(n_pad / 64); g2.c0 = 0; g2.c1 = (int)(n_pad / 64); g2.lower = 0;
+  return launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g2);
+}
+
 int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma, const double* MSigma, int64_t ldsigma,
                    int grad_mode, double* nlml, double grad[2]) {
-  if (!h || !theta || !nlml) return fail(h, SIGP_BAD_ARG, "nlml_grad: bad argument");
+  if (!h || !theta || !nlml || h->n == 0) return fail(h, SIGP_BAD_ARG, "nlml_grad: bad argument");
+  if (grad_mode < 0 || grad_mode > 2) return fail(h, SIGP_BAD_ARG, "nlml_grad: grad_mode must be 0, 1 (reference formulae) or 2 (exact)");
+  if (grad_mode != 0 && !grad) return fail(h, SIGP_BAD_ARG, "nlml_grad: grad buffer required");
+  if (grad_mode == 1 && kernel_id != SIGP_KERNEL_NETDIFFUSION) return fail(h, SIGP_BAD_ARG, "nlml_grad: the reference gradient formulae exist for the reference kernel only");
+  if (grad_mode != 0 && kernel_id == SIGP_KERNEL_NETDIFFUSION && !MSigma) return fail(h, SIGP_BAD_ARG, "nlml_grad: M @ Sigma~ required");
   const double inf = std::numeric_limits<double>::infinity();
-  if (grad_mode != 0) return fail(h, SIGP_BAD_ARG, "nlml_grad: gradient modes are not built yet (grad_mode must be 0)");
-  (void)MSigma;
+  const double ell = std::exp(theta[0]), snt = std::exp(theta[1]);
+  if (!std::isfinite(ell) || !std::isfinite(snt)) { *nlml = inf; if (grad) grad[0] = grad[1] = inf; return SIGP_NOT_SPD; }
   double out[4];
-  int rc = sigp_fit_predict(h, kernel_id, std::exp(theta[0]), std::exp(theta[1]), Sigma, ldsigma, out, nullptr, nullptr);
+  int rc = sigp_fit_predict(h, kernel_id, ell, snt, Sigma, ldsigma, out, nullptr, nullptr);
   if (rc == SIGP_NOT_SPD) { *nlml = inf; if (grad) grad[0] = grad[1] = inf; return rc; }
   if (rc) return rc;
   *nlml = out[1];
+  if (grad_mode == 0) return SIGP_OK;
+
+  // ---- K13/K14: tr(K~^-1 dK~) and A~^T dK~ A~ -------------------------------------------------------
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long n = h->n, n_pad = h->n_pad, ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  const double sf = out[0];
+  if ((rc = ensure(h, &h->gU, &h->cap_gU, n_pad * n_pad))) return rc;
+  if ((rc = ensure(h, &h->gK, &h->cap_gK, n_pad * n_pad))) return rc;
+  if ((rc = ensure(h, &h->gD, &h->cap_gD, n_pad * n_pad))) return rc;
+  if ((rc = ensure(h, &h->gPart, &h->cap_gPart, 4 * n_pad))) return rc;
+  if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, (long)RIDE * n_pad))) return rc;
+  // U = L~^-T: every 128-row chunk of the identity through the forward block solve, chunks in lockstep
+  {
+    const long tot = n_pad * n_pad;
+    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->gU, ld, (int)n_pad);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = solve_rows_forward(h, s, h->gU, n_pad, T))) return rc;
+  }
+  // -K~^-1 = -(U U^T) on the lower 128-tiles (the trailing-update kernel, K = n_pad)
+  {
+    HIPCHK(h, hipMemsetAsync(h->gK, 0, (size_t)n_pad * n_pad * sizeof(double), st));
+    GemmArgs g{};
+    g.A = h->gU; g.lda = ld; g.B = h->gU; g.ldb = ld; g.C = h->gK; g.ldc = ld; g.K = (int)n_pad;
+    g.r0 = 0; g.r1 = T; g.c0 = 0; g.c1 = T; g.lower = 1;
+    if ((rc = launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g))) return rc;
+  }
+  // A~ = L~^-T z by the backward block solve of the ride row
+  HIPCHK(h, hipMemsetAsync(h->scratchZ, 0, (size_t)RIDE * n_pad * sizeof(double), st));
+  HIPCHK(h, hipMemcpyAsync(h->scratchZ, s.mat + n_pad * ld, (size_t)n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
+  if ((rc = solve_rows_backward(h, s, h->scratchZ, n_pad))) return rc;
+  // dK~_1 (full symmetric): the reference's X (M Sigma~) X^T, or d k~/d log l for RBF / Matern
+  if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
+    if ((rc = build_xsxt(h, MSigma, ldsigma, h->gD))) return rc;
+  } else {
+    s.kps_host[0] = make_kparams(kernel_id == SIGP_KERNEL_RBF ? KID_RBF_DLOGL : KID_MATERN52_DLOGL, ell, 0.0, 0);
+    if ((rc = upload_kparams(h, s, 1))) return rc;
+    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), 1);
+    hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
+    HIPCHK(h, hipGetLastError());
+  }
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)n), dim3(256), 0, st, h->gK, h->gD, h->scratchZ, ld, (int)n, h->gPart);
+  HIPCHK(h, hipGetLastError());
+  std::vector<double> part((size_t)4 * n);
+  HIPCHK(h, hipMemcpyAsync(part.data(), h->gPart, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  double Td = 0, Qd = 0, trKinv = 0, aa = 0;   // T(D) = tr(K~^-1 D), Q(D) = A~^T D A~, tr(K~^-1), A~^T A~
+  for (long i = 0; i < n; ++i) { Td += part[4 * i]; Qd += part[4 * i + 1]; trKinv += part[4 * i + 2]; aa += part[4 * i + 3]; }
+  if (grad_mode == 1) {
+    // reference formulae (north/June1st.py:248-252) with K = sf K~, alpha = A~/sf:
+    //   dK_l = sf [X (M S~) X^T + sn~ I],  dK_s = sf [X S~ X^T + I],  X S~ X^T = K~ - sn~ I
+    grad[0] = 0.5 * (Td + snt * trKinv) - (Qd + snt * aa) / (2.0 * sf);
+    const double T2 = (double)n - snt * trKinv + trKinv;            // tr(K~^-1 (K~ - sn~ I + I))
+    const double Q2 = (double)n * sf - snt * aa + aa;               // A~^T (K~ - sn~ I + I) A~, A~^T K~ A~ = y^T A~ = n sf
+    grad[1] = 0.5 * T2 - Q2 / (2.0 * sf);
+  } else {
+    // exact derivative of the profiled nlML: d/dtheta = 1/2 tr(K~^-1 dK~) - A~^T dK~ A~ / (2 sf)
+    const double scale1 = (kernel_id == SIGP_KERNEL_NETDIFFUSION) ? ell : 1.0;   // dK~/dlog l = l X (M S~) X^T
+    grad[0] = scale1 * (0.5 * Td - Qd / (2.0 * sf));
+    grad[1] = snt * (0.5 * trKinv - aa / (2.0 * sf));
+  }
   return SIGP_OK;
 }
 

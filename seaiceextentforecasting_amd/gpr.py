@@ -168,22 +168,48 @@ class GPR:
         return mean, var
 
     # ---- MLII (north/June1st.py:235-257) -------------------------------------------------------
-    def nlml(self, theta, grad=None):
-        """``MLII(hyperparameters)``: theta = (log l, log sn~) -> (nlML, grad[2]).  Non-SPD K~ gives
-        ``(inf, [inf, inf])`` like the reference's except branch (:254-256).  ``grad`` None returns the
-        value only (gradient entry None); 'ref' / 'exact' gradients are not built on the device yet."""
+    def nlml(self, theta, grad="ref"):
+        """``MLII(hyperparameters)``: theta = (log l, log sn~) -> (nlML, grad[2]).
+
+        grad='ref'   the reference's own formulae (:248-252; NOT the derivative of nlML, SURVEY App. C-7;
+                     defined for the reference kernel only),
+        grad='exact' the analytic derivative of the profiled nlML (what an optimiser should be given),
+        grad=None    value only (second entry None).
+        A non-SPD K~ or an overflowing exp(theta) gives ``(inf, [inf, inf])`` like the reference's except
+        branch (:254-256).  Everything O(n^3) runs on the device (K13/K14: tr(K~^-1 dK~) from a lockstep
+        forward block solve of the identity + one SYRK)."""
         if not self._has_data:
             raise RuntimeError("nlml: no data staged; call fit() or set_data() first")
-        if grad not in (None,):
-            raise NotImplementedError("nlml gradient mode %r is not built yet (K13/K14)" % (grad,))
-        theta = np.asarray(theta, dtype=np.float64).reshape(2)
-        try:
-            with np.errstate(over="raise"):
-                ell, snt = float(np.exp(theta[0])), float(np.exp(theta[1]))
-            self.refit(ell, snt)
-        except (LinAlgError, ValueError, OverflowError, FloatingPointError):
-            return np.inf, np.asarray([np.inf, np.inf])
-        return np.float64(self.nlml_), None
+        if grad not in (None, "ref", "exact"):
+            raise ValueError("grad must be None, 'ref' or 'exact'")
+        if grad == "ref" and self.kernel != "netdiffusion":
+            raise ValueError("grad='ref' is defined for the reference kernel only")
+        theta = L.f64(np.asarray(theta, dtype=np.float64).reshape(2), 1)
+        inf2 = (np.inf, np.asarray([np.inf, np.inf]))
+        with np.errstate(over="ignore"):
+            ell = float(np.exp(theta[0]))
+        if not np.isfinite(ell) or not np.isfinite(np.exp(theta[1])):
+            return inf2
+        Sig = MSig = None
+        if self.kernel == "netdiffusion":
+            try:
+                with np.errstate(over="raise", invalid="raise"):
+                    Sig = L.f64(sigma_tilde(self._M, ell), 2)
+                    MSig = L.f64(self._M @ Sig, 2)
+            except (ValueError, OverflowError, FloatingPointError):
+                return inf2
+            if not (np.all(np.isfinite(Sig)) and np.all(np.isfinite(MSig))):
+                return inf2
+        mode = {None: 0, "ref": 1, "exact": 2}[grad]
+        val = C.c_double()
+        g = np.zeros(2)
+        self._fitted = False
+        rc = self._lib.sigp_nlml_grad(self._h, self._kid, L.ptr(theta), L.ptr(Sig), L.ptr(MSig),
+                                      0 if Sig is None else Sig.shape[1], mode, C.byref(val), L.ptr(g))
+        if rc == L.NOT_SPD:
+            return inf2
+        self._check(rc, "nlml")
+        return np.float64(val.value), (None if grad is None else g)
 
     # ---- state accessors -----------------------------------------------------------------------
     @property

@@ -122,17 +122,57 @@ def test_golden_intermediates(S, golden):
             assert abs(gp.nlml_ - nl_ref) <= 1e-9 * abs(nl_ref)
 
 
-def test_mlii_contract_value_and_inf_branch(S, golden):
-    """gp.nlml(theta) == the reference's live MLII closure (value), and the except-branch -> (inf, [inf, inf])."""
-    r = golden["records"][0]
-    with S.GPR(kernel="netdiffusion") as gp:
-        gp.set_data(r["X"], r["y"], M=r["M"])
-        for th, nl in zip(r["mlii_theta"], r["mlii_nlml"]):
-            val, grad = gp.nlml(th)
-            if np.isinf(nl):
-                assert np.isinf(val) and np.all(np.isinf(grad))
-            else:
+def test_mlii_contract_against_reference_closure(S, golden):
+    """gp.nlml(theta, grad='ref') == the reference's live MLII closure: value, its 2-vector "gradient"
+    (north/June1st.py:248-252) and the except-branch -> (inf, [inf, inf])."""
+    for r in golden["records"][:2]:
+        with S.GPR(kernel="netdiffusion") as gp:
+            gp.set_data(r["X"], r["y"], M=r["M"])
+            cond = np.linalg.cond(r["L_tilde"]) ** 2
+            for th, nl, gr in zip(r["mlii_theta"], r["mlii_nlml"], r["mlii_grad"]):
+                val, grad = gp.nlml(th, grad="ref")
+                if np.isinf(nl):
+                    assert np.isinf(val) and np.all(np.isinf(grad))
+                    continue
+                if np.exp(th[0]) > 1e6:
+                    continue      # l = 3.1e10: expm(l M) moves by ~1e-6 under 1-ulp changes of l (SURVEY App. C-11)
                 assert abs(val - nl) <= 1e-9 * abs(nl)
+                # the reference sums tr(solve(L.T, solve(L, dK))) in LU arithmetic: both sides carry cond(K)*eps
+                tol = max(1e-7, 1e3 * 2.3e-16 * np.linalg.cond(O.fit_predict(r["X"], r["y"], r["Xs"], float(np.exp(th[0])), float(np.exp(th[1])), M=r["M"], ref_idiom=False)["K_tilde"]))
+                assert np.max(np.abs(grad - gr)) <= tol * max(1.0, np.max(np.abs(gr))), (th, grad, gr)
+            del cond
+
+
+@pytest.mark.parametrize("kind", ["netdiffusion", "rbf", "matern52"])
+def test_exact_gradient_matches_oracle_and_finite_differences(S, kind):
+    rng = np.random.default_rng(5)
+    n, N = 150, 6
+    X = rng.standard_normal((n, N))
+    y = X @ rng.standard_normal(N) + 0.3 * rng.standard_normal(n)
+    th = {"netdiffusion": np.array([np.log(0.14), np.log(6.1)]), "rbf": np.array([0.5, -1.0]), "matern52": np.array([0.8, -0.5])}[kind]
+    with S.GPR(kernel=kind) as gp:
+        gp.set_data(X, y)
+        f0, g0 = gp.nlml(th, grad="exact")
+        fo, go = O.mlii(th, X, y, kind=kind, grad="exact")
+        assert abs(f0 - fo) <= 1e-9 * abs(fo)
+        assert np.allclose(g0, go, rtol=1e-7, atol=1e-9), (g0, go)
+        h = 1e-5
+        fd = np.array([(gp.nlml(th + h * e, grad=None)[0] - gp.nlml(th - h * e, grad=None)[0]) / (2 * h) for e in np.eye(2)])
+        assert np.allclose(g0, fd, rtol=1e-5, atol=1e-6), (g0, fd)
+        if kind != "netdiffusion":
+            with pytest.raises(ValueError):
+                gp.nlml(th, grad="ref")
+
+
+def test_exact_gradient_n1024(S):
+    """K13/K14 at a multi-block size: lockstep forward solve of the identity (8 chunks) + SYRK."""
+    X, y, _ = O.synthetic_problem(1024, 8, 42, m=1)
+    th = np.array([np.log(np.sqrt(8.0)), np.log(1e-2)])
+    with S.GPR(kernel="rbf") as gp:
+        gp.set_data(X, y)
+        f0, g0 = gp.nlml(th, grad="exact")
+    fo, go = O.mlii(th, X, y, kind="rbf", grad="exact")
+    assert abs(f0 - fo) <= 1e-9 * abs(fo) and np.allclose(g0, go, rtol=1e-7, atol=1e-8), (g0, go)
 
 
 def test_not_spd_raises_linalgerror_with_pivot(S):
