@@ -115,6 +115,23 @@ int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo);
 int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma,
                    const double* MSigma, int64_t ldsigma, int grad_mode, double* nlml, double grad[2]);
 
+/* One large fit sharded over GPUs (BASELINE configs[3]): 1-D block-cyclic ownership of outer panels
+ * (W column blocks of 128); the host side (dist.DistributedGPR) moves factored panels between ranks with
+ * torch.distributed (RCCL broadcast over xGMI on the GPU box).  Every rank holds the whole matrix buffer but
+ * only updates the panels it owns; a factored panel is packed into a contiguous device buffer, broadcast,
+ * and unpacked by the other ranks.  J, W, c0, c1 are in units of 128-column blocks.
+ * Replaces the same np.linalg.cholesky call (north/June1st.py:265) as sigp_potrf. */
+int sigp_dist_begin(sigp_handle* h);                                   /* after sigp_kernel_build*: reset info  */
+int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W);  /* doubles in the packed panel J..J+W     */
+int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info);  /* owner: factor panel       */
+int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf);    /* matrix -> contiguous buf  */
+int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf); /* buf -> matrix + dinv  */
+/* trailing update of column blocks [J+W+c0, J+W+c1) with panel J..J+W (only the caller's own panels) */
+int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1);
+/* after the last panel: reductions + results, as sigp_fit_predict's out/mean/var; marks the handle fitted */
+int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var);
+int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_pad / 128                        */
+
 /* measurement ---------------------------------------------------------------------------------- */
 /* enable=1: bracket every kernel launch with HIP events on the stream it is launched on and
  * accumulate per kernel class; enable=0: off (default).  sigp_profile_get drains finished events. */

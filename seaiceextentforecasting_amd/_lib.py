@@ -40,6 +40,14 @@ SIGNATURES = {
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
     "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, C.POINTER(C.c_double), _dp]),
+    "sigp_dist_begin": (C.c_int, [_h]),
+    "sigp_dist_panel_elems": (_i64, [_h, _i64, _i64]),
+    "sigp_dist_panel_factor": (C.c_int, [_h, _i64, _i64, C.POINTER(_i64)]),
+    "sigp_dist_panel_pack": (C.c_int, [_h, _i64, _i64, C.c_void_p]),
+    "sigp_dist_panel_unpack": (C.c_int, [_h, _i64, _i64, C.c_void_p]),
+    "sigp_dist_update": (C.c_int, [_h, _i64, _i64, _i64, _i64]),
+    "sigp_dist_finish": (C.c_int, [_h, _i64, _dp, _dp, _dp]),
+    "sigp_num_blocks": (_i64, [_h]),
     "sigp_profile": (C.c_int, [_h, C.c_int]),
     "sigp_profile_get": (C.c_int, [_h, C.c_int, _dp, C.POINTER(_i64), _dp, _dp]),
     "sigp_profile_reset": (C.c_int, [_h]),

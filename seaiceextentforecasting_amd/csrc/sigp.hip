@@ -27,7 +27,7 @@ constexpr int NB = 128;         // column-block width of the factorisation (= di
 constexpr int RIDE = 128;       // rows of the ride-along block
 constexpr int MAX_SLOTS = 16;
 
-struct ProfEvent { hipEvent_t a, b; int kclass; };
+struct ProfEvent { hipEvent_t a, b; int kclass; double flops; int K; };
 
 // One "slot" = everything one in-flight fit needs: the augmented matrix, inverse diagonal blocks, two
 // streams (update / panel) and result buffers.  Slot 0 backs the single-fit API.
@@ -85,6 +85,7 @@ struct sigp_handle {
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
   int opt_pan_priority = 1;  // panel streams at high priority
+  int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
@@ -212,10 +213,10 @@ void slot_free(Slot& s) {
 // ---- profiling brackets -------------------------------------------------------------------------
 struct ProfScope {
   sigp_handle* h; hipStream_t st; ProfEvent pe; bool on;
-  ProfScope(sigp_handle* h_, hipStream_t st_, int kclass, double flops, double bytes) : h(h_), st(st_), on(h_->prof) {
+  ProfScope(sigp_handle* h_, hipStream_t st_, int kclass, double flops, double bytes, int K = 0) : h(h_), st(st_), on(h_->prof) {
     h->p_flops[kclass] += flops; h->p_bytes[kclass] += bytes; h->p_n[kclass] += 1;
     if (on) {
-      pe.kclass = kclass;
+      pe.kclass = kclass; pe.flops = flops; pe.K = K;
       (void)hipEventCreate(&pe.a); (void)hipEventCreate(&pe.b);
       (void)hipEventRecord(pe.a, st);
     }
@@ -230,6 +231,7 @@ void prof_drain(sigp_handle* h) {
     (void)hipEventSynchronize(pe.b);
     float ms = 0;
     if (hipEventElapsedTime(&ms, pe.a, pe.b) == hipSuccess) h->p_ms[pe.kclass] += ms;
+    if (h->opt_host_timing >= 2) fprintf(stderr, "[sigp-launch] class %d K %d gflop %.3f ms %.4f tflops %.2f\n", pe.kclass, pe.K, pe.flops * 1e-9, ms, pe.flops / (ms * 1e-3) * 1e-12);
     (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b);
   }
   h->pev.clear();
@@ -252,18 +254,20 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
   return SIGP_OK;
 }
 
-int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
+template <bool SET>
+int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(syrk128_kernel, dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
+  hipLaunchKernelGGL(syrk128_kernel<SET>, dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
+int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) { return launch_syrk128_t<false>(h, st, g); }
 
 // C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
 int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
@@ -273,7 +277,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */)
   if (nt <= 0) return SIGP_OK;
   const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * 8;
   if (nt >= h->opt_small_tiles && h->opt_syrk_v2) {
-    ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
+    ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
     return launch_syrk128(h, st, g);
   }
   if (nt >= h->opt_small_tiles) {
@@ -370,8 +374,13 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
       g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
       g.C = M + o * ld + (long)c * NB; g.ldc = ld;
       g.batch = nb; g.sA = g.sC = s.matStride; g.sB = s.dinvStride;
-      g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+      g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
+      if (rows_below * nb >= h->opt_trsm128) {   // enough 128-row tiles to fill the chip: the LDS-DMA kernel
+        g.r1 = rows_below;
+        return launch_syrk128_t<true>(h, sp, g);
+      }
+      g.r1 = rows_below * 4;                     // few rows: 32-row tiles for parallelism
       return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
     }
     const int hw = Wp / 2;
@@ -414,6 +423,45 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
     HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
   }
   return SIGP_OK;
+}
+
+// stand-alone pieces of potrf_slot for the multi-GPU driver (one member, slot stream, no look-ahead)
+int dist_update(sigp_handle* h, Slot& s, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB), R = T + 1;
+  const long o = (long)ccol0 * NB;
+  GemmArgs g{};
+  g.A = s.mat + o * ld + (long)kcol0 * NB; g.lda = ld;
+  g.B = g.A; g.ldb = ld;
+  g.C = s.mat + o * ld + o; g.ldc = ld;
+  g.batch = 1; g.sA = g.sB = g.sC = 0;
+  g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = 0;
+  return gemm_sub_auto(h, s.s_upd, g);
+}
+
+int dist_panel(sigp_handle* h, Slot& s, long n_pad, int J0, int Wp) {
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB), R = T + 1;
+  hipStream_t sp = s.s_upd;
+  if (Wp == 1) {
+    const int c = J0;
+    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, s.mat + (long)c * NB * ld + (long)c * NB, ld,
+                       s.dinv + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
+    HIPCHK(h, hipGetLastError());
+    const long o = (long)(c + 1) * NB;
+    const int rows_below = R - (c + 1);
+    GemmArgs g{};
+    g.A = s.mat + o * ld + (long)c * NB; g.lda = ld;
+    g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
+    g.C = s.mat + o * ld + (long)c * NB; g.ldc = ld;
+    g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+  }
+  const int hw = Wp / 2;
+  int rc = dist_panel(h, s, n_pad, J0, hw);
+  if (rc) return rc;
+  if ((rc = dist_update(h, s, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
+  return dist_panel(h, s, n_pad, J0 + hw, Wp - hw);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
@@ -511,6 +559,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     }
     return SIGP_OK;
   }
+  if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
@@ -1116,6 +1165,93 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
     grad[0] = scale1 * (0.5 * Td - Qd / (2.0 * sf));
     grad[1] = snt * (0.5 * trKinv - aa / (2.0 * sf));
   }
+  return SIGP_OK;
+}
+
+// ---- one large fit sharded over GPUs: panel-level entry points (host side: dist.DistributedGPR) ------------
+int64_t sigp_num_blocks(sigp_handle* h) { return h ? h->n_pad / NB : 0; }
+
+int sigp_dist_begin(sigp_handle* h) {
+  if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "dist_begin: build the kernel matrix first");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  static bool diag_attr = false;
+  if (!diag_attr) {
+    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    diag_attr = true;
+  }
+  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
+  return sync_slot(h, s);
+}
+
+static bool dist_args_ok(sigp_handle* h, int64_t J, int64_t W) {
+  return h && h->n > 0 && J >= 0 && W >= 1 && J + W <= h->n_pad / NB;
+}
+
+int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W) {
+  if (!dist_args_ok(h, J, W)) return -1;
+  const long rows = h->n_pad + RIDE - J * NB;          // rows J*128 .. end (ride block included)
+  return rows * W * NB + W * NB * NB;                  // panel + the W inverse diagonal blocks
+}
+
+int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info) {
+  if (!dist_args_ok(h, J, W)) return fail(h, SIGP_BAD_ARG, "dist_panel_factor: bad panel");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc = dist_panel(h, s, h->n_pad, (int)J, (int)W);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
+  if ((rc = sync_slot(h, s))) return rc;
+  if (info) *info = *s.info_host;
+  return SIGP_OK;
+}
+
+int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf) {
+  if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_pack: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
+  double* buf = (double*)dev_buf;
+  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * 8, s.mat + J * NB * ld + J * NB, (size_t)ld * 8, (size_t)wcols * 8, (size_t)rows,
+                             hipMemcpyDeviceToDevice, s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, s.dinv + J * NB * NB, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_upd));
+  return sync_slot(h, s);
+}
+
+int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf) {
+  if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_unpack: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
+  const double* buf = (const double*)dev_buf;
+  HIPCHK(h, hipMemcpy2DAsync(s.mat + J * NB * ld + J * NB, (size_t)ld * 8, buf, (size_t)wcols * 8, (size_t)wcols * 8, (size_t)rows,
+                             hipMemcpyDeviceToDevice, s.s_upd));
+  HIPCHK(h, hipMemcpyAsync(s.dinv + J * NB * NB, buf + rows * wcols, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_upd));
+  return sync_slot(h, s);
+}
+
+int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1) {
+  if (!dist_args_ok(h, J, W) || c0 < 0 || c1 < c0 || J + W + c1 > h->n_pad / NB) return fail(h, SIGP_BAD_ARG, "dist_update: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc = dist_update(h, s, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
+  if (rc) return rc;
+  return sync_slot(h, s);
+}
+
+int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var) {
+  if (!h || !out || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_finish: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  int rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m);
+  if (rc) return rc;
+  if ((rc = sync_slot(h, s))) return rc;
+  h->fit_res.assign(s.res_host, s.res_host + 512);
+  finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+  h->built = false;
+  h->factored = h->fitted = (info == 0);
+  h->sigma_f = out[0]; h->nlml = out[1];
+  if (info != 0) return fail(h, SIGP_NOT_SPD, "dist_finish: matrix is not positive definite (pivot %d)", (int)info);
   return SIGP_OK;
 }
 

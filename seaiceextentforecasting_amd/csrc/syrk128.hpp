@@ -22,6 +22,9 @@ constexpr int SY_LDS_BYTES = 2 * 2 * SY_T * KT * (int)sizeof(double);   // 2 buf
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 
+// SET = false:  C -= A B^T   (trailing / inner updates)
+// SET = true :  C  = A B^T   (panel solve L21 = A21 inv(L11)^T, in place: a tile reads only its own rows of A = C)
+template <bool SET>
 __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* As = smem;                       // [2][128][16]
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = -Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr];
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = SET ? 0.0 : -Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr];
 
   // DMA coordinates: per wave-instruction 8 rows x 128 B; lane -> (row = lane>>3, slot' = lane&7)
   const int drow = wave * 8 + (lane >> 3);                 // + 32*p
@@ -126,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr] = -acc[i][j][r];
+      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
   if (g.stamp && tid == 0) {
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;

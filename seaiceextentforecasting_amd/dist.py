@@ -2,6 +2,8 @@
 round-robin over ranks, every rank factorises its share on its own GPU with no data-path collective, and the
 few floats per fit (sigma_f, nlml, info, mean, var) are all-gathered at the end over torch.distributed
 (backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+import ctypes as C
+
 import numpy as np
 
 
@@ -61,3 +63,88 @@ def fit_batch_sharded(engine, X, y, Xs, ell, sn_tilde, rank, world, dist=None):
         sigma_f=np.zeros(0), nlml=np.zeros(0), info=np.zeros(0, np.int64), sigma_n=np.zeros(0),
         mean=np.zeros((0, 0 if Xs is None else np.asarray(Xs).shape[-2])), var=np.zeros((0, 0 if Xs is None else np.asarray(Xs).shape[-2])))
     return gather_results(r, F, rank, world, dist)
+
+
+class DistributedGPR:
+    """One large fit sharded over the GPUs of a node (BASELINE configs[3]): 1-D block-cyclic ownership
+    of outer panels (``outer_blocks`` x 128 columns).  Per panel: the owner factors it (diagonal blocks, panel
+    solve, panel-internal updates), the factored panel -- rows below it, the ride-along rows and the inverse
+    diagonal blocks -- is broadcast (``torch.distributed``: RCCL over xGMI with backend "nccl"), and every rank
+    applies the rank-K update to the panels it owns.  After the last panel every rank holds the whole factor and
+    the solved ride rows, so sigma_f / nlML / predictions are formed locally with no further collective.
+
+    Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277)."""
+
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4):
+        from .gpr import GPR
+        import torch
+        self._torch = torch
+        self.rank, self.world, self.dist = int(rank), int(world), dist
+        self.W = int(outer_blocks)
+        self.gp = GPR(kernel=kernel, device=device)
+        self.device = device
+        self._buf = None
+
+    def close(self):
+        self.gp.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def owner(self, panel_index):
+        return panel_index % self.world
+
+    def fit(self, X, y, ell, sn_tilde, M=None, Xs=None):
+        from . import _lib as L
+        from .gpr import LinAlgError
+        torch, gp, lib = self._torch, self.gp, self.gp._lib
+        gp.set_data(X, y, M=M, Xs=Xs)          # X, y replicated on every rank (n*d*8 bytes)
+        gp.build(ell, sn_tilde)                # every rank builds K~; it only ever updates the panels it owns
+        gp._check(lib.sigp_dist_begin(gp._h), "dist_begin")
+        T = int(lib.sigp_num_blocks(gp._h))
+        panels = [(J, min(self.W, T - J)) for J in range(0, T, self.W)]
+        nmax = max(int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels) + 1
+        if self._buf is None or self._buf.numel() < nmax:
+            self._buf = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
+        info = 0
+        for p, (J, Wc) in enumerate(panels):
+            own = self.owner(p)
+            ne = int(lib.sigp_dist_panel_elems(gp._h, J, Wc))
+            view = self._buf[:ne + 1]
+            if self.rank == own:
+                pinfo = C.c_int64(0)
+                gp._check(lib.sigp_dist_panel_factor(gp._h, J, Wc, C.byref(pinfo)), "dist_panel_factor")
+                gp._check(lib.sigp_dist_panel_pack(gp._h, J, Wc, C.c_void_p(view.data_ptr())), "dist_panel_pack")
+                view[ne] = float(pinfo.value)
+            if self.world > 1:
+                self.dist.broadcast(view, src=own)       # the block-row panel broadcast (RCCL over xGMI)
+            torch.cuda.synchronize(self.device)
+            info = int(view[ne].item())
+            if info != 0:
+                break
+            if self.rank != own:
+                gp._check(lib.sigp_dist_panel_unpack(gp._h, J, Wc, C.c_void_p(view.data_ptr())), "dist_panel_unpack")
+            for q in range(p + 1, len(panels)):        # rank-K update of the panels this rank owns
+                if self.owner(q) == self.rank:
+                    Jq, Wq = panels[q]
+                    c0 = Jq - (J + Wc)
+                    gp._check(lib.sigp_dist_update(gp._h, J, Wc, c0, c0 + Wq), "dist_update")
+        out = np.zeros(4)
+        m = 0 if gp._ride is None else gp._ride.shape[0]
+        mean, var = np.zeros(max(m, 1)), np.zeros(max(m, 1))
+        rc = lib.sigp_dist_finish(gp._h, info, L.ptr(out), L.ptr(mean), L.ptr(var))
+        gp.info_ = info
+        if rc == L.NOT_SPD:
+            raise LinAlgError("Matrix is not positive definite (pivot %d)" % info, info)
+        gp._check(rc, "dist_finish")
+        gp.sigma_f_, gp.nlml_, gp.sigma_n_ = float(out[0]), float(out[1]), float(out[3])
+        gp._ride_mean, gp._ride_var = mean[:m].copy(), var[:m].copy()
+        gp._fitted = True
+        self.sigma_f_, self.nlml_, self.sigma_n_ = gp.sigma_f_, gp.nlml_, gp.sigma_n_
+        return self
+
+    def predict(self, Xs):
+        return self.gp.predict(Xs)

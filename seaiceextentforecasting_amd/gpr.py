@@ -230,13 +230,21 @@ class GPR:
         """L = chol(K) = sqrt(sigma_f) L~ (north/June1st.py:270)."""
         return np.sqrt(self.sigma_f_) * self.L_tilde_
 
-    def kernel_matrix(self, ell, sn_tilde):
-        """K~ (lower triangle) as built on the device -- test/diagnostic accessor."""
+    def build(self, ell, sn_tilde):
+        """K5 only: K~ (+ ride rows) into HBM; the factorisation is driven separately (potrf / DistributedGPR)."""
+        if not self._has_data:
+            raise RuntimeError("build: no data staged")
         if self.kernel == "netdiffusion":
             Sig = L.f64(sigma_tilde(self._M, float(ell)), 2)
             self._check(self._lib.sigp_kernel_build_from_sigma(self._h, L.ptr(Sig), Sig.shape[1], float(sn_tilde)), "kernel_build")
         else:
             self._check(self._lib.sigp_kernel_build(self._h, self._kid, float(ell), float(sn_tilde)), "kernel_build")
+        self.ell_, self.sn_tilde_ = float(ell), float(sn_tilde)
+        self._fitted = False
+
+    def kernel_matrix(self, ell, sn_tilde):
+        """K~ (lower triangle) as built on the device -- test/diagnostic accessor."""
+        self.build(ell, sn_tilde)
         out = np.zeros((self.n, self.n))
         self._check(self._lib.sigp_get_matrix(self._h, 0, L.ptr(out), self.n), "get_matrix")
         self._fitted = False

@@ -293,3 +293,48 @@ def test_full_size_properties_n8192_batch(S):
         assert np.max(np.abs(Krows @ at - yb[0][rows])) <= 1e-8 * np.max(np.abs(yb[0]))
         mu2, var2 = gp.predict(Xb[0][:3])                                 # predicting at training points ~ interpolation
         assert np.all(var2 > 0) and np.all(np.abs(mu2 - yb[0][:3]) < 1.0)
+
+
+_DIST_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")          # 2 ranks share the box's single GPU: gloo moves the panels (RCCL needs 2 devices)
+for kind, n, d, W in (("rbf", 1100, 8, 2), ("netdiffusion", 700, 12, 1), ("matern52", 515, 4, 3)):
+    X, y, Xs = O.synthetic_problem(n, d, 4242 + n, m=3)
+    ell, sn = (np.sqrt(d), 1e-2) if kind != "netdiffusion" else (0.05, 1e-2)
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W) as dg:
+        dg.fit(X, y, ell, sn, Xs=Xs)
+        mu, var = dg.predict(Xs)
+        mu2, var2 = dg.predict(Xs[:2] + 0.1)
+        L = dg.gp.L_tilde_
+    ref2 = O.fit_predict(X, y, Xs[:2] + 0.1, ell, sn, kind=kind, M=ref["M"], ref_idiom=False)
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+    assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank)
+    assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank)
+    assert rel(dg.nlml_, ref["nlml"]) <= 1e-9 and rel(L, ref["L_tilde"]) <= 1e-11, (kind, rank)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_sharded_cholesky_panel_broadcast(tmp_path, world):
+    """BASELINE configs[3] path at test size: block-cyclic panels over `world` ranks with the panel broadcast
+    (gloo here, two processes on the one GPU; RCCL on a multi-GPU node) == oracle on every rank."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text(_DIST_WORKER % dict(root=root, out=str(tmp_path)))
+    port = 29600 + (os.getpid() % 300) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=500)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert (tmp_path / ("ok_%d" % r)).exists()
