@@ -18,17 +18,41 @@ namespace sigp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int KT = 16;        // k-slice per LDS stage
-constexpr int LDP = KT + 2;   // LDS pitch (doubles) of a [row][k] image
+// Element-type traits.  A K-slice is always 128 bytes per row (16 doubles / 32 floats) and a staging access is
+// always 16 bytes, so the byte geometry of every LDS image and DMA is the same for fp64 and fp32.
+// MFMA 16x16x4: A/B one element per lane (row/col = lane&15, k = lane>>4); D rows differ:
+//   f64: row = (lane>>4) + 4*reg      f32: row = 4*(lane>>4) + reg
+template <typename T> struct Num;
+template <> struct Num<double> {
+  typedef d4 acc_t;  typedef d2 v16_t;  typedef d2 v2_t;
+  static constexpr int NE = 2;        // elements per 16 bytes
+  static constexpr int KT = 16;       // k-slice per LDS stage
+  static constexpr int LDP = 18;      // LDS pitch (elements) of a [row][k] image: conflict-free 8-byte fragment reads
+  __device__ static inline acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+  __device__ static inline int drow(int lq, int r) { return lq + 4 * r; }
+};
+template <> struct Num<float> {
+  typedef f4 acc_t;  typedef f4 v16_t;  typedef f2 v2_t;
+  static constexpr int NE = 4;
+  static constexpr int KT = 32;
+  static constexpr int LDP = 36;      // 144-byte rows (16-byte aligned); 4-byte fragment reads are 2-way conflicted
+  __device__ static inline acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  __device__ static inline int drow(int lq, int r) { return 4 * lq + r; }
+};
+
+constexpr int KT = Num<double>::KT;   // (fp64 names kept for the fp64-only call sites)
 
 enum { GEMM_SUB = 0, GEMM_SET = 1 };
 
-struct GemmArgs {
-  const double* A; long lda;   // A is M x K row-major (K contiguous)
-  const double* B; long ldb;   // B is N x K row-major (BT=false) or K x N row-major (BT=true)
-  double* C; long ldc;
-  int K;                       // multiple of 16
+template <typename T>
+struct GemmArgsT {
+  const T* A; long lda;        // A is M x K row-major (K contiguous)
+  const T* B; long ldb;        // B is N x K row-major (BT=false) or K x N row-major (BT=true)
+  T* C; long ldc;
+  int K;                       // multiple of the K-slice (16 doubles / 32 floats)
   int batch;                   // grid.y (0 or 1 = single problem)
   long sA, sB, sC;             // batch strides (elements): blockIdx.y selects the batch member
   // tile space in units of (TM, TN): columns bj in [c0,c1), rows bi in [max(r0, lower ? bj : r0), r1)
@@ -38,6 +62,7 @@ struct GemmArgs {
   int dbg;                     // timing ablations (debug only): 1 no global loads in loop, 2 no LDS stores, 4 no barrier
   int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD
 };
+typedef GemmArgsT<double> GemmArgs;
 
 // number of tiles of the (possibly trapezoidal) tile space; shared by host and device
 __host__ __device__ inline int gemm_tile_count(int r0, int r1, int c0, int c1, int lower) {
@@ -67,7 +92,8 @@ __host__ __device__ inline int gemm_grid_size(int r0, int r1, int c0, int c1, in
   return (np + 7) / 8 * 8 * patch * patch;
 }
 
-__device__ inline bool gemm_tile_coords(const GemmArgs& g, int b, int& bi, int& bj) {
+template <typename T>
+__device__ inline bool gemm_tile_coords(const GemmArgsT<T>& g, int b, int& bi, int& bj) {
   if (!g.lower) {
     int nr = g.r1 - g.r0;
     bj = g.c0 + b / nr;
@@ -103,24 +129,28 @@ __device__ inline bool gemm_tile_coords(const GemmArgs& g, int b, int& bi, int& 
   return bj < g.c1 && bi < g.r1 && bi >= bj && bi >= g.r0;
 }
 
-template <int TM, int TN, bool BT>
+template <typename T, int TM, int TN, bool BT>
 constexpr int gemm_lds_bytes() {
-  return (2 * TM * LDP + (BT ? 2 * KT * (TN + 16) : 2 * TN * LDP)) * (int)sizeof(double);
+  return (2 * TM * Num<T>::LDP + (BT ? 2 * Num<T>::KT * (TN + 16) : 2 * TN * Num<T>::LDP)) * (int)sizeof(T);
 }
 
-template <int TM, int TN, int WM, int WN, int MODE, bool BT>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
+template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   static_assert(WM * WN == 4, "4 waves");
+  typedef Num<T> N_;
+  typedef typename N_::acc_t acc_t;
+  typedef typename N_::v16_t v16_t;
+  constexpr int KTe = N_::KT, LDPe = N_::LDP, NE = N_::NE;
   constexpr int WTM = TM / WM, WTN = TN / WN;
   constexpr int FM = WTM / 16, FN = WTN / 16;
-  constexpr int PA = TM / 32;   // d2 loads per thread per stage for A (TM rows x 16 k = TM*8 d2)
+  constexpr int PA = TM / 32;   // 16-byte loads per thread per stage for A (TM rows x 128 B)
   constexpr int PB = TN / 32;
   constexpr int BTP = TN + 16;  // pitch of the [k][n] image (BT)
   static_assert(FM >= 1 && FN >= 1 && PA >= 1 && PB >= 1, "tile too small");
 
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* As = smem;                  // [2][TM][LDP]
-  double* Bs = smem + 2 * TM * LDP;   // [2][TN][LDP]  or  [2][KT][BTP]
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = (T*)smem_raw;               // [2][TM][LDP]
+  T* Bs = As + 2 * TM * LDPe;         // [2][TN][LDP]  or  [2][KT][BTP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -129,78 +159,79 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
   int bi, bj;
   if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
   const long bz = blockIdx.y;
-  const double* Ag = g.A + bz * g.sA + (long)bi * TM * g.lda;
-  const double* Bg = BT ? g.B + bz * g.sB + (long)bj * TN : g.B + bz * g.sB + (long)bj * TN * g.ldb;
-  double* Cg = g.C + bz * g.sC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
+  const T* Ag = g.A + bz * g.sA + (long)bi * TM * g.lda;
+  const T* Bg = BT ? g.B + bz * g.sB + (long)bj * TN : g.B + bz * g.sB + (long)bj * TN * g.ldb;
+  T* Cg = g.C + bz * g.sC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
 
-  d4 acc[FM][FN];
+  acc_t acc[FM][FN];
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
       if (MODE == GEMM_SUB) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr];
       } else {
-        acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
       }
     }
 
-  // staging coordinates
-  const int arow = tid >> 3, acp = (tid & 7) * 2;                 // [row][k] images: 8 lanes per 128-B row
-  constexpr int BT_TPR = TN / 2;                                   // threads per k-row of the [k][n] image
-  const int bkr = tid / BT_TPR, bcp = (tid % BT_TPR) * 2;
+  // staging coordinates: 8 lanes x 16 B per 128-byte row slice
+  const int arow = tid >> 3, acp = (tid & 7) * NE;
+  constexpr int BT_TPR = TN / NE;                                  // threads per k-row of the [k][n] image
+  const int bkr = tid / BT_TPR, bcp = (tid % BT_TPR) * NE;
   constexpr int BT_RPP = 256 / BT_TPR;                             // k-rows per pass
 
-  d2 va[PA], vb[PB];
+  v16_t va[PA], vb[PB];
 #define SIGP_GLOAD(k0)                                                                         \
   {                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PA; ++p)                                             \
-        va[p] = *(const d2*)(Ag + (long)(arow + 32 * p) * g.lda + (k0) + acp);                 \
+        va[p] = *(const v16_t*)(Ag + (long)(arow + 32 * p) * g.lda + (k0) + acp);              \
     if (BT) {                                                                                  \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          vb[p] = *(const d2*)(Bg + (long)((k0) + bkr + BT_RPP * p) * g.ldb + bcp);            \
+          vb[p] = *(const v16_t*)(Bg + (long)((k0) + bkr + BT_RPP * p) * g.ldb + bcp);         \
     } else {                                                                                   \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          vb[p] = *(const d2*)(Bg + (long)(arow + 32 * p) * g.ldb + (k0) + acp);               \
+          vb[p] = *(const v16_t*)(Bg + (long)(arow + 32 * p) * g.ldb + (k0) + acp);            \
     }                                                                                          \
   }
 #define SIGP_SSTORE(buf)                                                                       \
   {                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                           \
-      d2 t = va[p];                                                                            \
+      v16_t t = va[p];                                                                         \
       if (MODE == GEMM_SUB) t = -t;                                                            \
-      *(d2*)(As + ((buf) * TM + arow + 32 * p) * LDP + acp) = t;                               \
+      *(v16_t*)(As + ((buf) * TM + arow + 32 * p) * LDPe + acp) = t;                           \
     }                                                                                          \
     if (BT) {                                                                                  \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          *(d2*)(Bs + ((buf) * KT + bkr + BT_RPP * p) * BTP + bcp) = vb[p];                    \
+          *(v16_t*)(Bs + ((buf) * KTe + bkr + BT_RPP * p) * BTP + bcp) = vb[p];                \
     } else {                                                                                   \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          *(d2*)(Bs + ((buf) * TN + arow + 32 * p) * LDP + acp) = vb[p];                       \
+          *(v16_t*)(Bs + ((buf) * TN + arow + 32 * p) * LDPe + acp) = vb[p];                   \
     }                                                                                          \
   }
 
-  const int nst = g.K / KT;
+  const int nst = g.K / KTe;
   SIGP_GLOAD(0);
   SIGP_SSTORE(0);
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst && !(g.dbg & 1)) SIGP_GLOAD((s + 1) * KT);
-    const double* Ab = As + (buf * TM + wm * WTM + lr) * LDP + lq;
-    const double* Bb = BT ? Bs + (buf * KT + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDP + lq;
+    if (s + 1 < nst && !(g.dbg & 1)) SIGP_GLOAD((s + 1) * KTe);
+    const T* Ab = As + (buf * TM + wm * WTM + lr) * LDPe + lq;
+    const T* Bb = BT ? Bs + (buf * KTe + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDPe + lq;
 #pragma unroll
-    for (int kk = 0; kk < KT / 4; ++kk) {
-      double a[FM], b[FN];
+    for (int kk = 0; kk < KTe / 4; ++kk) {
+      T a[FM], b[FN];
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = Ab[i * 16 * LDP + kk * 4];
+      for (int i = 0; i < FM; ++i) a[i] = Ab[i * 16 * LDPe + kk * 4];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = BT ? Bb[kk * 4 * BTP + j * 16] : Bb[j * 16 * LDP + kk * 4];
+      for (int j = 0; j < FN; ++j) b[j] = BT ? Bb[kk * 4 * BTP + j * 16] : Bb[j * 16 * LDPe + kk * 4];
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < FN; ++j) acc[i][j] = N_::mfma(a[i], b[j], acc[i][j]);
     }
     if (s + 1 < nst && !(g.dbg & 2)) SIGP_SSTORE(buf ^ 1);
     if (!(g.dbg & 4)) __syncthreads();
@@ -213,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + lq + 4 * r) * g.ldc + j * 16 + lr] = acc[i][j][r];
+      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = acc[i][j][r];
 }
 
 }  // namespace sigp

@@ -32,9 +32,11 @@ __device__ inline double cov_from_sq(const KParams& kp, double sq) {
 constexpr int KB_T = 64;    // tile
 constexpr int KB_DC = 32;   // feature chunk staged in LDS
 // blockIdx.z = batch member; its hyper-parameters and data set come from kps[z].
+template <typename TO>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
-                                                     double* __restrict__ Mat, long strideM, long ld,
+                                                     TO* __restrict__ Mat, long strideM, long ld,
                                                      const KParams* __restrict__ kps, int full) {
+  typedef typename Num<TO>::v2_t v2_t;
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (bj > bi && !full) return;   // full = 1: every tile, zero (not identity) on the padding (derivative matrices)
   const KParams kp = kps[blockIdx.z];
@@ -75,24 +77,25 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int gi = bi * KB_T + rg + 8 * s, gj = bj * KB_T + c2;
-    d2 v;
+    v2_t v;
     if (gi >= n) {
-      v.x = (gi == gj && !full) ? 1.0 : 0.0;
-      v.y = (gi == gj + 1 && !full) ? 1.0 : 0.0;
+      v.x = (TO)((gi == gj && !full) ? 1.0 : 0.0);
+      v.y = (TO)((gi == gj + 1 && !full) ? 1.0 : 0.0);
     } else {
-      v.x = (gj < n) ? cov_from_sq(kp, acc[s][0]) + (gi == gj ? kp.sn : 0.0) : 0.0;
-      v.y = (gj + 1 < n) ? cov_from_sq(kp, acc[s][1]) + (gi == gj + 1 ? kp.sn : 0.0) : 0.0;
+      v.x = (TO)((gj < n) ? cov_from_sq(kp, acc[s][0]) + (gi == gj ? kp.sn : 0.0) : 0.0);
+      v.y = (TO)((gj + 1 < n) ? cov_from_sq(kp, acc[s][1]) + (gi == gj + 1 ? kp.sn : 0.0) : 0.0);
     }
-    *(d2*)(Mat + (long)gi * ld + gj) = v;
+    *(v2_t*)(Mat + (long)gi * ld + gj) = v;
   }
 }
 
 // Ride-along block (128 rows x n_pad): row 0 = y (may be null -> zeros), rows 1..m = k~(xs_j, x_i)
 // (north/June1st.py:272 KXXs^T in unit signal variance), remaining rows 0.  first_row lets predict()
 // fill rows 0..m-1 with cross-covariances only (y == nullptr, first_row = 0).
+template <typename TO>
 __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restrict__ X, long strideX, const double* __restrict__ Xs,
                                                          long strideXs, const double* __restrict__ y, long stridey, int dp, int d,
-                                                         int n, int n_pad, int m, int first_row, double* __restrict__ Z,
+                                                         int n, int n_pad, int m, int first_row, TO* __restrict__ Z,
                                                          long strideZ, long ld, const KParams* __restrict__ kps, int compute_cov) {
   const int i = blockIdx.x * 256 + threadIdx.x;   // column (training point)
   const int r = blockIdx.y;                       // row of the ride block
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restric
       return;   // rows were produced by a GEMM (reference kernel); only row 0 / padding handled here
     }
   }
-  Z[(long)r * ld + i] = v;
+  Z[(long)r * ld + i] = (TO)v;
 }
 
 // after a GEMM-form build (reference kernel): add sn on the diagonal, identity on the padding
@@ -154,8 +157,9 @@ __device__ inline double block_reduce_sum(double v, double* sh) {
 //   res[256]     = sum_i<n log L~_ii (north/June1st.py:246)
 // grid = nrows + 1 blocks of 256 threads.
 // blockIdx.y = batch member (strides sW, sZ, sM; res += 512*y).
-__global__ __launch_bounds__(256) void epilogue_kernel(const double* __restrict__ W, long ldw, const double* __restrict__ zrow,
-                                                       const double* __restrict__ Mat, long ld, int n, int n_pad, int nrows,
+template <typename TI>
+__global__ __launch_bounds__(256) void epilogue_kernel(const TI* __restrict__ W, long ldw, const TI* __restrict__ zrow,
+                                                       const TI* __restrict__ Mat, long ld, int n, int n_pad, int nrows,
                                                        double* __restrict__ res, long sW, long sZ, long sM) {
   __shared__ double sh[4];
   const int r = blockIdx.x;
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* __restrict_
   if (r < nrows) {
     double a = 0.0, b = 0.0;
     for (int i = threadIdx.x; i < n_pad; i += 256) {
-      const double w = W[(long)r * ldw + i];
-      a += w * zrow[i];
+      const double w = (double)W[(long)r * ldw + i];
+      a += w * (double)zrow[i];
       b += w * w;
     }
     a = block_reduce_sum(a, sh);
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const double* __restrict_
     if (threadIdx.x == 0) { res[r] = a; res[128 + r] = b; }
   } else if (Mat != nullptr) {
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) a += log(Mat[(long)i * ld + i]);
+    for (int i = threadIdx.x; i < n; i += 256) a += log((double)Mat[(long)i * ld + i]);
     a = block_reduce_sum(a, sh);
     if (threadIdx.x == 0) res[256] = a;
   }
@@ -222,6 +226,128 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
     part[4 * i + 2] = -Kneg[(long)i * ld + i];
     part[4 * i + 3] = a[i] * a[i];
   }
+}
+
+// ---- fp32 factor + fp64 iterative refinement (BASELINE configs[4]) -----------------------------------
+// fp64 residual of the refinement, with the covariance recomputed on the fly (no n x n fp64 matrix is ever stored):
+//   Rout[r][i] = Bq[r][i] - sum_j ( k~(x_i, x_j) + sn [i==j] ) Xq[r][j]        r < nrhs <= 4, i < n
+// Bq row r is: r == 0 -> y, r >= 1 -> k~(xs_{r-1}, .) (recomputed).  One thread per i (x_i in registers, DREG
+// features), x_j tiles of 64 rows broadcast from LDS.
+template <int DREG>
+__global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
+                                                               const double* __restrict__ y, int dp, int n, int nrhs,
+                                                               const double* __restrict__ Xq, long ldq, double* __restrict__ Rout,
+                                                               long ldr, KParams kp) {
+  __shared__ double Xj[64][DREG + 1];
+  __shared__ double Q[4][64];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double xi[DREG];
+#pragma unroll
+  for (int p = 0; p < DREG; ++p) xi[p] = (i < n) ? X[(long)i * dp + p] : 0.0;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int j0 = 0; j0 < n; j0 += 64) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 64 * DREG; idx += 256) {
+      const int jj = idx / DREG, p = idx % DREG;
+      Xj[jj][p] = (j0 + jj < n) ? X[(long)(j0 + jj) * dp + p] : 0.0;
+    }
+    {
+      const int r = threadIdx.x >> 6, jj = threadIdx.x & 63;
+      Q[r][jj] = (r < nrhs && j0 + jj < n) ? Xq[(long)r * ldq + j0 + jj] : 0.0;
+    }
+    __syncthreads();
+    const int jn = min(64, n - j0);
+    for (int jj = 0; jj < jn; ++jj) {
+      double sq = 0.0;
+#pragma unroll
+      for (int p = 0; p < DREG; ++p) { const double t = xi[p] - Xj[jj][p]; sq = fma(t, t, sq); }
+      double kv = cov_from_sq(kp, sq);
+      if (j0 + jj == i) kv += kp.sn;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = fma(kv, Q[r][jj], acc[r]);
+    }
+  }
+  if (i >= n) return;
+  for (int r = 0; r < nrhs; ++r) {
+    double b;
+    if (r == 0) {
+      b = y[i];
+    } else {
+      const double* xs = Xs + (long)(r - 1) * dp;
+      double sq = 0.0;
+#pragma unroll
+      for (int p = 0; p < DREG; ++p) { const double t = xs[p] - xi[p]; sq = fma(t, t, sq); }
+      b = cov_from_sq(kp, sq);
+    }
+    Rout[(long)r * ldr + i] = b - acc[r];
+  }
+}
+
+// dst[r][i] (TO) <- src[r][i] (TI), rows x cols, different strides; zero beyond cols_valid
+template <typename TI, typename TO>
+__global__ void convert_rows_kernel(const TI* __restrict__ src, long lds, TO* __restrict__ dst, long ldd, int rows, int cols,
+                                    int cols_valid) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx % cols);
+  dst[(long)r * ldd + c] = (c < cols_valid) ? (TO)src[(long)r * lds + c] : (TO)0;
+}
+
+// Xacc[r][i] += (double) D[r][i]
+template <typename TI>
+__global__ void accumulate_rows_kernel(const TI* __restrict__ D, long ldd, double* __restrict__ Xacc, long ldx, int rows, int cols) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx % cols);
+  Xacc[(long)r * ldx + c] += (double)D[(long)r * ldd + c];
+}
+
+// final fp64 dots of the refined solutions: out[r] = B_r . Xq_0 (r=0: y.alpha~; r>=1: k*_r . alpha~), out[4+r] = B_r . Xq_r
+// (k*_r . w_r), out[8] = max_r ||R_r||_inf proxy is computed on the host from the residual rows
+template <int DREG>
+__global__ __launch_bounds__(256) void krefine_dots_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
+                                                           const double* __restrict__ y, int dp, int n, int nrhs,
+                                                           const double* __restrict__ Xq, long ldq, double* __restrict__ part,
+                                                           KParams kp) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  double xi[DREG];
+#pragma unroll
+  for (int p = 0; p < DREG; ++p) xi[p] = (i < n) ? X[(long)i * dp + p] : 0.0;
+  for (int r = 0; r < nrhs; ++r) {
+    double b = 0.0;
+    if (i < n) {
+      if (r == 0) b = y[i];
+      else {
+        const double* xs = Xs + (long)(r - 1) * dp;
+        double sq = 0.0;
+#pragma unroll
+        for (int p = 0; p < DREG; ++p) { const double t = xs[p] - xi[p]; sq = fma(t, t, sq); }
+        b = cov_from_sq(kp, sq);
+      }
+    }
+    double v0 = (i < n) ? b * Xq[i] : 0.0;
+    double v1 = (i < n) ? b * Xq[(long)r * ldq + i] : 0.0;
+    v0 = block_reduce_sum(v0, sh);
+    v1 = block_reduce_sum(v1, sh);
+    if (threadIdx.x == 0) { part[(long)blockIdx.x * 8 + r] = v0; part[(long)blockIdx.x * 8 + 4 + r] = v1; }
+  }
+}
+
+// mean of new test points against the refined alpha~ (fp64): out[r] = sum_i k~(xs_r, x_i) alpha_i ; one block per point
+__global__ __launch_bounds__(256) void cross_mean_kernel(const double* __restrict__ X, const double* __restrict__ Xs, int dp, int d, int n,
+                                                         const double* __restrict__ alpha, double* __restrict__ out, KParams kp) {
+  __shared__ double sh[4];
+  const double* xs = Xs + (long)blockIdx.x * dp;
+  double a = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double* xi = X + (long)i * dp;
+    double sq = 0.0;
+    for (int p = 0; p < d; ++p) { const double t = xs[p] - xi[p]; sq = fma(t, t, sq); }
+    a = fma(cov_from_sq(kp, sq), alpha[i], a);
+  }
+  a = block_reduce_sum(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
 }  // namespace sigp

@@ -23,30 +23,37 @@ constexpr int BP = 18;    // pitch (doubles) inside a 16x16 LDS block: conflict-
 constexpr int BSZ = 16 * BP;
 // LDS holds only the 36 lower 16x16 blocks (block-packed) + the reciprocal diagonal: 84 KB, so the kernel can
 // share a CU with one resident trailing-update workgroup (64 KB) instead of waiting for a whole CU to drain.
-constexpr int DIAG_LDS_BYTES = (36 * BSZ + DB) * (int)sizeof(double);
+constexpr int DIAG_LDS_BYTES = (36 * BSZ + DB) * (int)sizeof(double);   // fp64 size; fp32 needs half
 constexpr int DIAG_THREADS = 512;
 
-__device__ inline double readlane_f64(double x, int l) {
+__device__ inline double readlane_t(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_readlane(lo, l);
   hi = __builtin_amdgcn_readlane(hi, l);
   return __hiloint2double(hi, lo);
 }
+__device__ inline float readlane_t(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+__device__ inline double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
+__device__ inline float rsq_seed(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BSZ; }   // bj <= bi
 
 // A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace whose
 // strictly-upper part is zero (zeroed once at allocation, never written here);
 // info: device word, first failing 1-based global pivot index (0 = none yet); pivot_base: global index of row 0.
 // blockIdx.x = batch member: A += b*strideA, Linv += b*strideL, info += b.
-__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __restrict__ A, long lda, double* __restrict__ Linv,
+template <typename T>
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv,
                                                                   int* __restrict__ info, int pivot_base, int skip, long strideA,
                                                                   long strideL) {
+  typedef Num<T> N_;
+  typedef typename N_::acc_t acc_t;
+  typedef typename N_::v2_t v2_t;
   A += blockIdx.x * strideA;
   Linv += blockIdx.x * strideL;
   info += blockIdx.x;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* S = smem;                  // 36 blocks of [16][18]
-  double* dinv = smem + 36 * BSZ;    // [128] reciprocals of the diagonal of L
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* S = (T*)smem_raw;               // 36 blocks of [16][18]
+  T* dinv = S + 36 * BSZ;            // [128] reciprocals of the diagonal of L
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -56,46 +63,46 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
     const int idx = tid + it * DIAG_THREADS;
     const int row = idx >> 6, cp = (idx & 63) * 2;
-    if (cp <= row) *(d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = *(const d2*)(A + (long)row * lda + cp);
+    if (cp <= row) *(v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = *(const v2_t*)(A + (long)row * lda + cp);
   }
   __syncthreads();
 
   // ---- factorisation, 8 steps of 16 columns ----
   for (int jb = 0; jb < 8; ++jb) {
-    double* Sjj = S + dblk(jb, jb);
+    T* Sjj = S + dblk(jb, jb);
     if (wave == 0 && !(skip & 1)) {
       // B1: 16x16 Cholesky; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by v_rsq_f64 + Goldschmidt
-      double r[16];
+      T r[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        double dj = readlane_f64(r[j], j);
-        if (!(dj > 0.0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
+        T dj = readlane_t(r[j], j);
+        if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
           if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
-          dj = 1.0;
+          dj = (T)1;
         }
-        const double y0 = __builtin_amdgcn_rsq(dj);
-        double g = dj * y0, hh = 0.5 * y0;
-        double e = fma(-hh, g, 0.5);
+        const T y0 = rsq_seed(dj);
+        T g = dj * y0, hh = (T)0.5 * y0;
+        T e = fma(-hh, g, (T)0.5);
         g = fma(g, e, g); hh = fma(hh, e, hh);
-        e = fma(-hh, g, 0.5);
+        e = fma(-hh, g, (T)0.5);
         g = fma(g, e, g); hh = fma(hh, e, hh);
-        const double e2 = fma(-g, g, dj);
-        const double s = fma(e2, hh, g);      // sqrt(dj)
-        const double inv = hh + hh;           // 1/sqrt(dj)
-        const double lij = (lr == j) ? s : r[j] * inv;
+        const T e2 = fma(-g, g, dj);
+        const T s = fma(e2, hh, g);      // sqrt(dj)
+        const T inv = hh + hh;           // 1/sqrt(dj)
+        const T lij = (lr == j) ? s : r[j] * inv;
         r[j] = lij;
 #pragma unroll
         for (int c = j + 1; c < 16; ++c) {
-          const double lcj = readlane_f64(lij, c);
+          const T lcj = readlane_t(lij, c);
           r[c] = fma(-lij, lcj, r[c]);
         }
         if (lane == 0) dinv[jb * 16 + j] = inv;
       }
       if (lane < 16) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : 0.0;
+        for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : (T)0;
       }
     }
     __syncthreads();
@@ -103,8 +110,8 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     const int nrows = DB - (jb * 16 + 16);
     if (tid < nrows && !(skip & 2)) {
       const int row = jb * 16 + 16 + tid;
-      double* Sr = S + dblk(row >> 4, jb) + (row & 15) * BP;
-      double x[16];
+      T* Sr = S + dblk(row >> 4, jb) + (row & 15) * BP;
+      T x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) x[c] = Sr[c];
 #pragma unroll
@@ -129,30 +136,30 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
       int ti1 = 0; rem = two ? t + 8 : t;
       while (rem > ti1) { rem -= ti1 + 1; ++ti1; }
       const int tj1 = rem;
-      double* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
-      double* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
-      const double* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
-      const double* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
-      d4 acc0, acc1;
+      T* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
+      T* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
+      const T* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
+      const T* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
+      acc_t acc0, acc1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        acc0[r] = C0[(lq + 4 * r) * BP + lr];
-        acc1[r] = C1[(lq + 4 * r) * BP + lr];
+        acc0[r] = C0[N_::drow(lq, r) * BP + lr];
+        acc1[r] = C1[N_::drow(lq, r) * BP + lr];
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const double a0 = -A0[lr * BP + kk * 4 + lq];
-        const double b0 = B0[lr * BP + kk * 4 + lq];
-        const double a1 = -A1[lr * BP + kk * 4 + lq];
-        const double b1 = B1[lr * BP + kk * 4 + lq];
-        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+        const T a0 = -A0[lr * BP + kk * 4 + lq];
+        const T b0 = B0[lr * BP + kk * 4 + lq];
+        const T a1 = -A1[lr * BP + kk * 4 + lq];
+        const T b1 = B1[lr * BP + kk * 4 + lq];
+        acc0 = N_::mfma(a0, b0, acc0);
+        acc1 = N_::mfma(a1, b1, acc1);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) C0[(lq + 4 * r) * BP + lr] = acc0[r];
+      for (int r = 0; r < 4; ++r) C0[N_::drow(lq, r) * BP + lr] = acc0[r];
       if (two) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) C1[(lq + 4 * r) * BP + lr] = acc1[r];
+        for (int r = 0; r < 4; ++r) C1[N_::drow(lq, r) * BP + lr] = acc1[r];
       }
     }
     __syncthreads();
@@ -164,9 +171,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     const int idx = tid + it * DIAG_THREADS;
     const int row = idx >> 6, cp = (idx & 63) * 2;
     if (cp <= row) {
-      d2 v = *(const d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
-      if (cp + 1 > row) v.y = 0.0;
-      *(d2*)(A + (long)row * lda + cp) = v;
+      v2_t v = *(const v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
+      if (cp + 1 > row) v.y = (T)0;
+      *(v2_t*)(A + (long)row * lda + cp) = v;
     }
   }
 
@@ -175,10 +182,10 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   // ---- inverse: 16x16 diagonal-block inverses in place (columns of inv(L_bb) by forward substitution) ----
   if (wave < 2) {
     const int b = wave * 4 + lq, c = lr;
-    double* Sbb = S + dblk(b, b);
-    double x[16];
+    T* Sbb = S + dblk(b, b);
+    T x[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = (i == c) ? 1.0 : 0.0;
+    for (int i = 0; i < 16; ++i) x[i] = (i == c) ? (T)1 : (T)0;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       x[i] *= dinv[b * 16 + i];
@@ -196,23 +203,25 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
   for (int jb = 6; jb >= 0 && !(skip & 16); --jb) {
     const int nb = 7 - jb;
     const int ib = jb + 1 + wave;
-    d4 acc = d4{0, 0, 0, 0}, accb = d4{0, 0, 0, 0};
+    acc_t acc, accb;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { acc[r] = (T)0; accb[r] = (T)0; }
     if (wave < nb) {
       // two interleaved accumulation chains (even / odd p)
       for (int p = jb + 1; p <= ib; p += 2) {
         const bool hasb = (p + 1) <= ib;
         const int pb = hasb ? p + 1 : p;
-        const double* Xa = S + dblk(ib, p), *La = S + dblk(p, jb);
-        const double* Xb = S + dblk(ib, pb), *Lb = S + dblk(pb, jb);
+        const T* Xa = S + dblk(ib, p), *La = S + dblk(p, jb);
+        const T* Xb = S + dblk(ib, pb), *Lb = S + dblk(pb, jb);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const double a = Xa[lr * BP + kk * 4 + lq];      // X[ib][p] (row lr, k)
-          const double b = La[(kk * 4 + lq) * BP + lr];    // L[p][jb] (k, col lr)
-          double a2 = Xb[lr * BP + kk * 4 + lq];
-          const double b2 = Lb[(kk * 4 + lq) * BP + lr];
-          if (!hasb) a2 = 0.0;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-          accb = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, accb, 0, 0, 0);
+          const T a = Xa[lr * BP + kk * 4 + lq];      // X[ib][p] (row lr, k)
+          const T b = La[(kk * 4 + lq) * BP + lr];    // L[p][jb] (k, col lr)
+          T a2 = Xb[lr * BP + kk * 4 + lq];
+          const T b2 = Lb[(kk * 4 + lq) * BP + lr];
+          if (!hasb) a2 = (T)0;
+          acc = N_::mfma(a, b, acc);
+          accb = N_::mfma(a2, b2, accb);
         }
       }
       acc += accb;
@@ -220,21 +229,23 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     __syncthreads();   // every read of the original L[.][jb] is done
     if (wave < nb) {
       // park T in the (wave-private) destination block so it can be re-read in A-operand layout
-      double* D = S + dblk(ib, jb);
-      const double* Xjj = S + dblk(jb, jb);
+      T* D = S + dblk(ib, jb);
+      const T* Xjj = S + dblk(jb, jb);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) D[(lq + 4 * r) * BP + lr] = acc[r];
+      for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = acc[r];
       __builtin_amdgcn_wave_barrier();
       asm volatile("" ::: "memory");
-      d4 u = d4{0, 0, 0, 0};
+      acc_t u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) u[r] = (T)0;
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) {
-        const double a = -D[lr * BP + kk * 4 + lq];
-        const double b = Xjj[(kk * 4 + lq) * BP + lr];
-        u = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, u, 0, 0, 0);
+        const T a = -D[lr * BP + kk * 4 + lq];
+        const T b = Xjj[(kk * 4 + lq) * BP + lr];
+        u = N_::mfma(a, b, u);
       }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) D[(lq + 4 * r) * BP + lr] = u[r];
+      for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = u[r];
     }
     __syncthreads();
   }
@@ -245,9 +256,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(double* __rest
     const int idx = tid + it * DIAG_THREADS;
     const int row = idx >> 6, cp = (idx & 63) * 2;
     if (cp <= row) {
-      d2 v = *(const d2*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
-      if (cp + 1 > row) v.y = 0.0;
-      *(d2*)(Linv + row * DB + cp) = v;
+      v2_t v = *(const v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
+      if (cp + 1 > row) v.y = (T)0;
+      *(v2_t*)(Linv + row * DB + cp) = v;
     }
   }
 }

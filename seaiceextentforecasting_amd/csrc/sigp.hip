@@ -67,6 +67,13 @@ struct sigp_handle {
   double* gK = nullptr; long cap_gK = 0;
   double* gD = nullptr; long cap_gD = 0;
   double* gPart = nullptr; long cap_gPart = 0;
+  // fp32 engine (dtype == SIGP_F32): fp32 factor + fp64 iterative refinement (BASELINE configs[4])
+  float* fmat = nullptr; float* fdinv = nullptr; float* fZ = nullptr; long cap_f_npad = 0;
+  double* xq = nullptr;      // [4][n_pad] refined solutions: row 0 alpha~ = K~^-1 y, rows 1..m  w_j = K~^-1 k~*_j
+  double* rq = nullptr;      // [4][n_pad] fp64 residuals
+  double* fpart = nullptr;   // partial sums of the final dots
+  int opt_refine_iters = 3;
+  double refine_resid = 0;   // ||y - K~ alpha~||_inf / ||y||_inf after the last refinement step
   std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
   std::vector<double> fit_res;                // epilogue reductions of the last fit (host copy)
   Slot slots[MAX_SLOTS];
@@ -85,6 +92,7 @@ struct sigp_handle {
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
   int opt_pan_priority = 1;  // panel streams at high priority
+  int opt_panel_ll = 0;      // panels up to this width are factored left-looking (0 = binary recursion only)
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
@@ -238,12 +246,12 @@ void prof_drain(sigp_handle* h) {
 }
 
 // ---- GEMM launch ----------------------------------------------------------------------------------
-template <int TM, int TN, int WM, int WN, int MODE, bool BT>
-int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
+template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT>
+int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
-  auto kern = gemm_mfma_kernel<TM, TN, WM, WN, MODE, BT>;
-  constexpr int lds = gemm_lds_bytes<TM, TN, BT>();
+  auto kern = gemm_mfma_kernel<T, TM, TN, WM, WN, MODE, BT>;
+  constexpr int lds = gemm_lds_bytes<T, TM, TN, BT>();
   static bool attr_done = false;
   if (!attr_done) {
     HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -253,40 +261,44 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
+// fp64 shorthand used by the fp64-only call sites
+template <int TM, int TN, int WM, int WN, int MODE, bool BT>
+int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) { return launch_gemm_cfg<double, TM, TN, WM, WN, MODE, BT>(h, st, g); }
 
-template <bool SET>
-int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgs& g) {
+template <typename T, bool SET>
+int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
   static bool attr_done = false;
   if (!attr_done) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<T, SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
     attr_done = true;
   }
-  hipLaunchKernelGGL(syrk128_kernel<SET>, dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
+  hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
-int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) { return launch_syrk128_t<false>(h, st, g); }
+int launch_syrk128(sigp_handle* h, hipStream_t st, const GemmArgs& g) { return launch_syrk128_t<double, false>(h, st, g); }
 
 // C[rows r0..r1, cols c0..c1 in 128-units] -= A B^T with the tile shape picked from the tile count
-int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgs g /* in 128-units */) {
+template <typename T>
+int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units */) {
   const int nb = std::max(1, g.batch);
   const double nt1 = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
   const int nt = (int)nt1 * nb;
   if (nt <= 0) return SIGP_OK;
-  const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * 8;
-  if (nt >= h->opt_small_tiles && h->opt_syrk_v2) {
+  const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
+  if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
-    return launch_syrk128(h, st, g);
+    return launch_syrk128_t<T, false>(h, st, g);
   }
   if (nt >= h->opt_small_tiles) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
-    return launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+    return launch_gemm_cfg<T, 128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
   }
   ProfScope ps(h, st, SIGP_KC_UPDATE_SMALL, flops, bytes);
   g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
-  return launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
+  return launch_gemm_cfg<T, 64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
 }
 
 // ---- builds -----------------------------------------------------------------------------------------
@@ -312,10 +324,10 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
   const long ld = n_pad;
   ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
   dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), (unsigned)nb);
-  hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
+  hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
-  hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, s.s_upd, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
+  hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, s.s_upd, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
                      (int)n_pad, (int)m, 1, s.mat + n_pad * ld, s.matStride, ld, s.kps, 1);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -324,16 +336,17 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
 // ---- blocked Cholesky of the nb lockstep members of slot s (each augmented with its ride rows) --------
 // Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
 // GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
-int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
+template <typename Real>
+int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
   const int W = std::max(1, h->opt_outer);
-  double* M = s.mat;
+  constexpr int diag_lds = (36 * BSZ + DB) * (int)sizeof(Real);
   HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
   static bool diag_attr = false;
   if (!diag_attr) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds));
     diag_attr = true;
   }
   const bool la = h->opt_lookahead != 0;
@@ -347,11 +360,11 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
   // lower-trapezoid update  C[cols ccol0.., rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
   auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1) -> int {
     const long o = (long)ccol0 * NB;
-    GemmArgs g{};
+    GemmArgsT<Real> g{};
     g.A = M + o * ld + (long)kcol0 * NB; g.lda = ld;
     g.B = g.A; g.ldb = ld;
     g.C = M + o * ld + o; g.ldc = ld;
-    g.batch = nb; g.sA = g.sB = g.sC = s.matStride;
+    g.batch = nb; g.sA = g.sB = g.sC = matStride;
     g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
     (void)kclass;
     return gemm_sub_auto(h, st, g);
@@ -363,25 +376,35 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
       const int c = J0;
       {
         ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3, nb * 3.0 * NB * NB * 8);
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(nb), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, M + (long)c * NB * ld + (long)c * NB, ld,
-                           s.dinv + (long)c * NB * NB, s.info, c * NB, 0, s.matStride, s.dinvStride);
+        hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, M + (long)c * NB * ld + (long)c * NB, ld,
+                           dinvp + (long)c * NB * NB, s.info, c * NB, 0, matStride, dinvStride);
         HIPCHK(h, hipGetLastError());
       }
       const long o = (long)(c + 1) * NB;
       const int rows_below = R - (c + 1);   // 128-row blocks below the diagonal block (ride block included)
-      GemmArgs g{};
+      GemmArgsT<Real> g{};
       g.A = M + o * ld + (long)c * NB; g.lda = ld;
-      g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
+      g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
       g.C = M + o * ld + (long)c * NB; g.ldc = ld;
-      g.batch = nb; g.sA = g.sC = s.matStride; g.sB = s.dinvStride;
+      g.batch = nb; g.sA = g.sC = matStride; g.sB = dinvStride;
       g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
       if (rows_below * nb >= h->opt_trsm128) {   // enough 128-row tiles to fill the chip: the LDS-DMA kernel
         g.r1 = rows_below;
-        return launch_syrk128_t<true>(h, sp, g);
+        return launch_syrk128_t<Real, true>(h, sp, g);
       }
       g.r1 = rows_below * 4;                     // few rows: 32-row tiles for parallelism
-      return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+      return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+    }
+    if (h->opt_panel_ll && Wp <= h->opt_panel_ll) {
+      // left-looking inside a (sub)panel: column block c is updated once with all earlier columns of the panel
+      // (K = 128 (c-J0)), then factored: each panel column is read/written once and the average K doubles
+      for (int i = 0; i < Wp; ++i) {
+        int rc;
+        if (i > 0 && (rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, i, J0 + i, 0, 1))) return rc;
+        if ((rc = panel(J0 + i, 1))) return rc;
+      }
+      return SIGP_OK;
     }
     const int hw = Wp / 2;
     int rc = panel(J0, hw);
@@ -425,6 +448,10 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
   return SIGP_OK;
 }
 
+int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
+  return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad);
+}
+
 // stand-alone pieces of potrf_slot for the multi-GPU driver (one member, slot stream, no look-ahead)
 int dist_update(sigp_handle* h, Slot& s, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
   const long ld = n_pad;
@@ -445,7 +472,7 @@ int dist_panel(sigp_handle* h, Slot& s, long n_pad, int J0, int Wp) {
   hipStream_t sp = s.s_upd;
   if (Wp == 1) {
     const int c = J0;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, s.mat + (long)c * NB * ld + (long)c * NB, ld,
+    hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, s.mat + (long)c * NB * ld + (long)c * NB, ld,
                        s.dinv + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
     HIPCHK(h, hipGetLastError());
     const long o = (long)(c + 1) * NB;
@@ -470,7 +497,7 @@ int epilogue_slot(sigp_handle* h, Slot& s, int nb, long n, long n_pad, long m) {
   double* Z = s.mat + n_pad * ld;
   {
     ProfScope ps(h, s.s_upd, SIGP_KC_EPILOGUE, nb * 4.0 * (m + 1) * n, nb * 8.0 * (m + 2) * n);
-    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(m + 2), (unsigned)nb), dim3(256), 0, s.s_upd, Z, ld, Z, s.mat, ld, (int)n,
+    hipLaunchKernelGGL(epilogue_kernel<double>, dim3((unsigned)(m + 2), (unsigned)nb), dim3(256), 0, s.s_upd, Z, ld, Z, s.mat, ld, (int)n,
                        (int)n_pad, (int)(m + 1), s.res, s.matStride, s.matStride, s.matStride);
     HIPCHK(h, hipGetLastError());
   }
@@ -497,6 +524,188 @@ void finish_results(const double* res, int info, long n, long m, double sn_tilde
   }
 }
 
+template <typename Real>
+static int solve_rows_forward_t(sigp_handle* h, hipStream_t st, const Real* Mat, const Real* dinvp, Real* Z, long n_pad, int nchunks) {
+  // Z[128*nchunks][n_pad] <- Z L~^-T : per block column kb: Z[:,kb] = Z[:,kb] inv(L_kk)^T ; Z[:,kb+1:] -= Z[:,kb] L[kb+1:,kb]^T
+  // nchunks > 1: all 128-row chunks advance in lockstep (grid.y = chunk)
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  for (int kb = 0; kb < T; ++kb) {
+    GemmArgsT<Real> g{};
+    g.A = Z + (long)kb * NB; g.lda = ld; g.B = dinvp + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
+    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    g.batch = nchunks; g.sA = g.sC = (long)RIDE * ld; g.sB = 0;
+    int rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, st, g);
+    if (rc) return rc;
+    if (kb + 1 < T) {
+      GemmArgsT<Real> u{};
+      u.batch = nchunks; u.sA = u.sC = (long)RIDE * ld; u.sB = 0;
+      u.A = Z + (long)kb * NB; u.lda = ld;
+      u.B = Mat + (long)(kb + 1) * NB * ld + (long)kb * NB; u.ldb = ld;
+      u.C = Z + (long)(kb + 1) * NB; u.ldc = ld;
+      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = (T - kb - 1) * 2; u.lower = 0;
+      rc = launch_gemm_cfg<Real, 64, 64, 2, 2, GEMM_SUB, false>(h, st, u);
+      if (rc) return rc;
+    }
+  }
+  return SIGP_OK;
+}
+
+template <typename Real>
+static int solve_rows_backward_t(sigp_handle* h, hipStream_t st, const Real* Mat, const Real* dinvp, Real* Z, long n_pad) {
+  // Z[128][n_pad] <- Z L~^-1 : from the last block column: Z[:,kb] = Z[:,kb] inv(L_kk) ; Z[:, :kb] -= Z[:,kb] L[kb, :kb]
+  const long ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  for (int kb = T - 1; kb >= 0; --kb) {
+    GemmArgsT<Real> g{};
+    g.A = Z + (long)kb * NB; g.lda = ld; g.B = dinvp + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
+    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    int rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, true>(h, st, g);
+    if (rc) return rc;
+    if (kb > 0) {
+      GemmArgsT<Real> u{};
+      u.A = Z + (long)kb * NB; u.lda = ld;
+      u.B = Mat + (long)kb * NB * ld; u.ldb = ld;       // K x N image: rows kb*128.., all columns < kb*128
+      u.C = Z; u.ldc = ld;
+      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = kb * 2; u.lower = 0;
+      rc = launch_gemm_cfg<Real, 64, 64, 2, 2, GEMM_SUB, true>(h, st, u);
+      if (rc) return rc;
+    }
+  }
+  return SIGP_OK;
+}
+
+static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad, int nchunks = 1) {
+  return solve_rows_forward_t<double>(h, s.s_upd, s.mat, s.dinv, Z, n_pad, nchunks);
+}
+static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
+  return solve_rows_backward_t<double>(h, s.s_upd, s.mat, s.dinv, Z, n_pad);
+}
+
+// ---- fp32 engine: fp32 kernel matrix + Cholesky, fp64 iterative refinement of alpha~ and w_j -----------------
+// (BASELINE configs[4]; no reference counterpart -- the reference is fp64 NumPy.  Same outputs as the fp64 path:
+//  sigma_f, nlML, mean, var of north/June1st.py:267-277, 246.)
+int f32_reserve(sigp_handle* h, long n_pad) {
+  if (h->cap_f_npad >= n_pad) return SIGP_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  for (float** p : {&h->fmat, &h->fdinv, &h->fZ}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+  for (double** p : {&h->xq, &h->rq, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+  h->cap_f_npad = 0;
+  HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)(n_pad + RIDE) * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fdinv, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
+  HIPCHK(h, hipMemset(h->fdinv, 0, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fZ, (size_t)RIDE * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->xq, (size_t)4 * n_pad * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->rq, (size_t)4 * n_pad * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->fpart, (size_t)(n_pad / 256 + 1) * 8 * sizeof(double)));
+  HIPCHK(h, hipDeviceSynchronize());
+  h->cap_f_npad = n_pad;
+  return SIGP_OK;
+}
+
+#define SIGP_DREG_DISPATCH(d, CALL)            \
+  do {                                         \
+    if ((d) <= 8) { CALL(8); }                 \
+    else if ((d) <= 16) { CALL(16); }          \
+    else if ((d) <= 32) { CALL(32); }          \
+    else { CALL(64); }                         \
+  } while (0)
+
+// one fp32 fit on slot 0's streams from device-resident X [n_pad][dp], y [n_pad], Xs [128][dp] (m <= 3 ride points)
+int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
+            long dp, long n_pad, long m, double* out, double* mean, double* var) {
+  if (m > 3) return fail(h, SIGP_BAD_ARG, "fp32 engine: at most 3 ride-along test points (refinement solves 1+m systems)");
+  if (d > 64) return fail(h, SIGP_BAD_ARG, "fp32 engine: d <= 64 required");
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long ld = n_pad;
+  const int nrhs = (int)(1 + m);
+  int rc;
+  if ((rc = f32_reserve(h, n_pad))) return rc;
+  if ((rc = slot_reserve(h, s, NB, 1))) return rc;     // res / info / kps buffers only
+  const KParams kp = make_kparams(kernel_id, ell, sn, 0);
+  s.kps_host[0] = kp;
+  if ((rc = upload_kparams(h, s, 1))) return rc;
+  {
+    ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * n / 2 * (3.0 * d + 20), 8.0 * n * d + 2.0 * n * (n + 1));
+    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), 1);
+    hipLaunchKernelGGL(kbuild_kernel<float>, grid, dim3(256), 0, st, X, 0L, (int)dp, (int)d, (int)n, h->fmat, 0L, ld, s.kps, 0);
+    HIPCHK(h, hipGetLastError());
+    dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, 1);
+    hipLaunchKernelGGL(ride_build_kernel<float>, g2, dim3(256), 0, st, X, 0L, Xs, 0L, y, 0L, (int)dp, (int)d, (int)n, (int)n_pad, (int)m, 1,
+                       h->fmat + n_pad * ld, 0L, ld, s.kps, 1);
+    HIPCHK(h, hipGetLastError());
+  }
+  if ((rc = potrf_core<float>(h, s, h->fmat, 0, h->fdinv, 0, 1, n_pad))) return rc;
+  {
+    const float* Z = h->fmat + n_pad * ld;
+    hipLaunchKernelGGL(epilogue_kernel<float>, dim3((unsigned)(m + 2), 1), dim3(256), 0, st, Z, ld, Z, (const float*)h->fmat, ld, (int)n,
+                       (int)n_pad, (int)(m + 1), s.res, 0L, 0L, 0L);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  // x0 = L^-T (L^-1 b): the ride rows already hold L^-1 [y k*]; one backward block solve finishes them
+  HIPCHK(h, hipMemcpyAsync(h->fZ, h->fmat + n_pad * ld, (size_t)RIDE * n_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if ((rc = solve_rows_backward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad))) return rc;
+  {
+    const long tot = (long)nrhs * n_pad;
+    hipLaunchKernelGGL((convert_rows_kernel<float, double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld,
+                       nrhs, (int)n_pad, (int)n);
+    HIPCHK(h, hipGetLastError());
+  }
+  const unsigned nblk = (unsigned)((n + 255) / 256);
+  for (int it = 0; it <= h->opt_refine_iters; ++it) {
+    // r = b - K~ x in fp64, covariance recomputed on the fly
+#define CALL_RES(D) hipLaunchKernelGGL(krefine_residual_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->rq, ld, kp)
+    SIGP_DREG_DISPATCH(d, CALL_RES);
+#undef CALL_RES
+    HIPCHK(h, hipGetLastError());
+    if (it == h->opt_refine_iters) break;    // the last pass only measures the residual
+    HIPCHK(h, hipMemsetAsync(h->fZ, 0, (size_t)RIDE * n_pad * sizeof(float), st));
+    const long tot = (long)nrhs * n_pad;
+    hipLaunchKernelGGL((convert_rows_kernel<double, float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)h->rq, ld, h->fZ, ld,
+                       nrhs, (int)n_pad, (int)n);
+    HIPCHK(h, hipGetLastError());
+    if ((rc = solve_rows_forward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad, 1))) return rc;
+    if ((rc = solve_rows_backward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad))) return rc;
+    hipLaunchKernelGGL(accumulate_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld, nrhs,
+                       (int)n_pad);
+    HIPCHK(h, hipGetLastError());
+  }
+#define CALL_DOT(D) hipLaunchKernelGGL(krefine_dots_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->fpart, kp)
+  SIGP_DREG_DISPATCH(d, CALL_DOT);
+#undef CALL_DOT
+  HIPCHK(h, hipGetLastError());
+  std::vector<double> part((size_t)nblk * 8), r0((size_t)n), yh((size_t)n);
+  HIPCHK(h, hipMemcpyAsync(part.data(), h->fpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(r0.data(), h->rq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(yh.data(), y, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  const int info = *s.info_host;
+  const double inf = std::numeric_limits<double>::infinity();
+  if (info != 0) {
+    out[0] = inf; out[1] = inf; out[2] = (double)info; out[3] = inf;
+    for (long j = 0; j < m; ++j) { if (mean) mean[j] = std::nan(""); if (var) var[j] = std::nan(""); }
+    return SIGP_OK;
+  }
+  double dots0[4] = {0, 0, 0, 0}, dots1[4] = {0, 0, 0, 0};
+  for (unsigned b = 0; b < nblk; ++b)
+    for (int r = 0; r < nrhs; ++r) { dots0[r] += part[(size_t)b * 8 + r]; dots1[r] += part[(size_t)b * 8 + 4 + r]; }
+  double rmax = 0, ymax = 0;
+  for (long i = 0; i < n; ++i) { rmax = std::max(rmax, std::fabs(r0[i])); ymax = std::max(ymax, std::fabs(yh[i])); }
+  h->refine_resid = ymax > 0 ? rmax / ymax : 0.0;
+  const double sf = dots0[0] / (double)n;                                   // y^T alpha~ / n
+  out[0] = sf;
+  out[1] = 0.5 * n + s.res_host[256] + 0.5 * n * std::log(sf) + 0.5 * n * std::log(2.0 * M_PI);   // log-det from the fp32 factor
+  out[2] = 0.0; out[3] = sf * sn;
+  for (long j = 0; j < m; ++j) {
+    if (mean) mean[j] = dots0[1 + j];                                       // k*^T alpha~
+    if (var) var[j] = sf * (1.0 + sn - dots1[1 + j]);                       // k** + sn~ - k*^T K~^-1 k*
+  }
+  return SIGP_OK;
+}
+
 int sync_slot(sigp_handle* h, Slot& s) {
   HIPCHK(h, hipStreamSynchronize(s.s_upd));
   return SIGP_OK;
@@ -512,7 +721,7 @@ int sigp_version(void) { return 100; }
 int sigp_create(sigp_handle** out, int device_id, int dtype) {
   if (!out) return SIGP_BAD_ARG;
   *out = nullptr;
-  if (dtype != SIGP_F64) return SIGP_BAD_ARG;   // the f32 + refinement path (config 5) is not built yet
+  if (dtype != SIGP_F64 && dtype != SIGP_F32) return SIGP_BAD_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return SIGP_HIP_ERROR;
   if (hipSetDevice(device_id) != hipSuccess) return SIGP_HIP_ERROR;
@@ -532,7 +741,10 @@ int sigp_destroy(sigp_handle* h) {
   (void)hipDeviceSynchronize();
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
-  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart};
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->xq, h->rq, h->fpart};
+  if (h->fmat) (void)hipFree(h->fmat);
+  if (h->fdinv) (void)hipFree(h->fdinv);
+  if (h->fZ) (void)hipFree(h->fZ);
   for (double* p : bufs) if (p) (void)hipFree(p);
   delete h;
   return SIGP_OK;
@@ -559,6 +771,8 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     }
     return SIGP_OK;
   }
+  if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
@@ -592,7 +806,7 @@ int sigp_set_train(sigp_handle* h, const double* X, int64_t n, int64_t d, int64_
   if ((rc = ensure(h, &h->y, &h->cap_y, n_pad))) return rc;
   if ((rc = ensure(h, &h->Xs, &h->cap_Xs, (long)RIDE * dp))) return rc;
   if ((rc = ensure(h, &h->stage, &h->cap_stage, std::max<long>(n * ldx, n_pad)))) return rc;
-  if ((rc = slot_reserve(h, h->slots[0], n_pad, 1))) return rc;
+  if ((rc = slot_reserve(h, h->slots[0], h->dtype == SIGP_F64 ? n_pad : (long)NB, 1))) return rc;
   hipStream_t st = h->slots[0].s_upd;
   HIPCHK(h, hipMemcpyAsync(h->stage, X, (size_t)((n - 1) * ldx + d) * sizeof(double), hipMemcpyHostToDevice, st));
   {
@@ -634,6 +848,8 @@ int sigp_set_test(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs) {
 }
 
 int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde) {
+  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "kernel_build: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
+
   if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "kernel_build: call set_train first");
   if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "kernel_build: kernel_id must be RBF or MATERN52 (use kernel_build_from_sigma for the reference kernel)");
   if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "kernel_build: ell > 0 and sn_tilde >= 0 required");
@@ -700,7 +916,7 @@ static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t l
     if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
     s.kps_host[0] = h->kp;
     if ((rc = upload_kparams(h, s, 1))) return rc;
-    hipLaunchKernelGGL(ride_build_kernel, dim3((unsigned)((n_pad + 255) / 256), 1, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
+    hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((n_pad + 255) / 256), 1, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
                        (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, s.mat + n_pad * ld, 0L, ld, s.kps, 0);
     HIPCHK(h, hipGetLastError());
   }
@@ -708,6 +924,8 @@ static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t l
 }
 
 int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde) {
+  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "kernel_build_from_sigma: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
+
   if (!h || h->n == 0 || !Sigma || ldsigma < h->d) return fail(h, SIGP_BAD_ARG, "kernel_build_from_sigma: bad argument");
   if (!(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "sn_tilde >= 0 required");
   HIPCHK(h, hipSetDevice(h->device));
@@ -738,6 +956,8 @@ int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ld
 }
 
 int sigp_potrf(sigp_handle* h, int64_t* info) {
+  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "potrf: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
+
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "potrf: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
@@ -754,6 +974,8 @@ int sigp_potrf(sigp_handle* h, int64_t* info) {
 }
 
 int sigp_fit(sigp_handle* h, double* sigma_f, double* nlml) {
+  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "fit: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
+
   if (!h || !h->factored) return fail(h, SIGP_BAD_ARG, "fit: call potrf first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
@@ -783,6 +1005,20 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
   int rc;
+  if (h->dtype == SIGP_F32) {
+    if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "fp32 engine: RBF / MATERN52 only");
+    if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "ell > 0 and sn_tilde >= 0 required");
+    h->kp = make_kparams(kernel_id, ell, sn_tilde, 0);
+    h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
+    h->kss_unit.assign((size_t)h->m, 1.0);
+    if ((rc = f32_fit(h, kernel_id, ell, sn_tilde, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, out, mean, var))) return rc;
+    const int info32 = (int)out[2];
+    h->built = false;
+    h->factored = h->fitted = (info32 == 0);
+    h->sigma_f = out[0]; h->nlml = out[1];
+    if (info32 != 0) return fail(h, SIGP_NOT_SPD, "fit_predict: matrix is not positive definite (pivot %d)", info32);
+    return SIGP_OK;
+  }
   if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
     if (!Sigma) return fail(h, SIGP_BAD_ARG, "fit_predict: Sigma required for the reference kernel");
     rc = sigp_kernel_build_from_sigma(h, Sigma, ldsigma, sn_tilde);
@@ -813,60 +1049,13 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
 }
 
 // ---- forward / backward block solves on a scratch ride block (predict for new points, alpha) --------
-static int solve_rows_forward(sigp_handle* h, Slot& s, double* Z, long n_pad, int nchunks = 1) {
-  // nchunks > 1: Z holds nchunks*128 rows; all chunks advance in lockstep (grid.y = chunk)
-  // Z[128][n_pad] <- Z L~^-T  : per block column kb: Z[:,kb] = Z[:,kb] inv(L_kk)^T ; Z[:,kb+1:] -= Z[:,kb] L[kb+1:,kb]^T
-  const long ld = n_pad;
-  const int T = (int)(n_pad / NB);
-  hipStream_t st = s.s_upd;
-  for (int kb = 0; kb < T; ++kb) {
-    GemmArgs g{};
-    g.A = Z + (long)kb * NB; g.lda = ld; g.B = s.dinv + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
-    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
-    g.batch = nchunks; g.sA = g.sC = (long)RIDE * ld; g.sB = 0;
-    int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, st, g);
-    if (rc) return rc;
-    if (kb + 1 < T) {
-      GemmArgs u{};
-      u.batch = nchunks; u.sA = u.sC = (long)RIDE * ld; u.sB = 0;
-      u.A = Z + (long)kb * NB; u.lda = ld;
-      u.B = s.mat + (long)(kb + 1) * NB * ld + (long)kb * NB; u.ldb = ld;
-      u.C = Z + (long)(kb + 1) * NB; u.ldc = ld;
-      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = (T - kb - 1) * 2; u.lower = 0;
-      rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, u);
-      if (rc) return rc;
-    }
-  }
-  return SIGP_OK;
-}
-
-static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
-  // Z <- Z L~^-1 : from the last block column: Z[:,kb] = Z[:,kb] inv(L_kk) ; Z[:, :kb] -= Z[:,kb] L[kb, :kb]
-  const long ld = n_pad;
-  const int T = (int)(n_pad / NB);
-  hipStream_t st = s.s_upd;
-  for (int kb = T - 1; kb >= 0; --kb) {
-    GemmArgs g{};
-    g.A = Z + (long)kb * NB; g.lda = ld; g.B = s.dinv + (long)kb * NB * NB; g.ldb = NB; g.C = Z + (long)kb * NB; g.ldc = ld;
-    g.K = NB; g.r0 = 0; g.r1 = RIDE / 32; g.c0 = 0; g.c1 = 1; g.lower = 0;
-    int rc = launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, true>(h, st, g);
-    if (rc) return rc;
-    if (kb > 0) {
-      GemmArgs u{};
-      u.A = Z + (long)kb * NB; u.lda = ld;
-      u.B = s.mat + (long)kb * NB * ld; u.ldb = ld;       // K x N image: rows kb*128.., all columns < kb*128
-      u.C = Z; u.ldc = ld;
-      u.K = NB; u.r0 = 0; u.r1 = RIDE / 64; u.c0 = 0; u.c1 = kb * 2; u.lower = 0;
-      rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, true>(h, st, u);
-      if (rc) return rc;
-    }
-  }
-  return SIGP_OK;
-}
-
 int sigp_get_alpha(sigp_handle* h, double* alpha_tilde) {
   if (!h || !h->factored || !alpha_tilde) return fail(h, SIGP_BAD_ARG, "get_alpha: call potrf first");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->dtype == SIGP_F32) {   // the refined solution (row 0 of xq)
+    HIPCHK(h, hipMemcpy(alpha_tilde, h->xq, (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
+    return SIGP_OK;
+  }
   Slot& s = h->slots[0];
   const long n_pad = h->n_pad, ld = n_pad;
   int rc;
@@ -882,6 +1071,42 @@ int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, doub
   if (!h || !h->fitted || !Xs || m < 1 || ldxs < h->d || !mean || !var) return fail(h, SIGP_BAD_ARG, "predict: bad argument or fit() not called");
   if (h->kernel_id == SIGP_KERNEL_NETDIFFUSION && !h->T) return fail(h, SIGP_BAD_ARG, "predict: no Sigma state");
   HIPCHK(h, hipSetDevice(h->device));
+  if (h->dtype == SIGP_F32) {
+    // mean = k*^T alpha~ in fp64 against the refined alpha~; variance from the fp32 factor (forward block solve)
+    Slot& s = h->slots[0];
+    hipStream_t st = s.s_upd;
+    const long n = h->n, n_pad = h->n_pad, ld = n_pad, dp = h->dp;
+    const long xs_off = RIDE * std::max<long>(ldxs, dp);
+    int rc;
+    if ((rc = ensure(h, &h->stage, &h->cap_stage, xs_off + RIDE * dp))) return rc;
+    double* xs_dev = h->stage + xs_off;
+    for (long c0 = 0; c0 < m; c0 += RIDE) {
+      const long mc = std::min<long>(RIDE, m - c0);
+      HIPCHK(h, hipMemcpyAsync(h->stage, Xs + c0 * ldxs, (size_t)((mc - 1) * ldxs + h->d) * sizeof(double), hipMemcpyHostToDevice, st));
+      const long tot = RIDE * dp;
+      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldxs, (int)mc, (int)h->d, xs_dev, RIDE, (int)dp);
+      HIPCHK(h, hipGetLastError());
+      s.kps_host[0] = h->kp;
+      if ((rc = upload_kparams(h, s, 1))) return rc;
+      dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, 1);
+      hipLaunchKernelGGL(ride_build_kernel<float>, g2, dim3(256), 0, st, h->X, 0L, xs_dev, 0L, (const double*)nullptr, 0L, (int)dp, (int)h->d, (int)n,
+                         (int)n_pad, (int)mc, 0, h->fZ, 0L, ld, s.kps, 1);
+      HIPCHK(h, hipGetLastError());
+      if ((rc = solve_rows_forward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad, 1))) return rc;
+      hipLaunchKernelGGL(epilogue_kernel<float>, dim3((unsigned)(mc + 1), 1), dim3(256), 0, st, (const float*)h->fZ, ld, (const float*)h->fZ, (const float*)nullptr, ld,
+                         (int)n, (int)n_pad, (int)mc, s.res, 0L, 0L, 0L);
+      HIPCHK(h, hipGetLastError());
+      hipLaunchKernelGGL(cross_mean_kernel, dim3((unsigned)mc), dim3(256), 0, st, h->X, xs_dev, (int)dp, (int)h->d, (int)n, (const double*)h->xq, s.res + 256 + 8, h->kp);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      for (long j = 0; j < mc; ++j) {
+        mean[c0 + j] = s.res_host[256 + 8 + j];
+        var[c0 + j] = h->sigma_f * (1.0 + h->sn_tilde - s.res_host[128 + j]);
+      }
+    }
+    return SIGP_OK;
+  }
   Slot& s = h->slots[0];
   const long n = h->n, n_pad = h->n_pad, ld = n_pad, dp = h->dp;
   int rc;
@@ -926,12 +1151,12 @@ int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, doub
       dim3 g2((unsigned)((n_pad + 255) / 256), RIDE);
       s.kps_host[0] = h->kp;
       if ((rc = upload_kparams(h, s, 1))) return rc;
-      hipLaunchKernelGGL(ride_build_kernel, g2, dim3(256), 0, st, h->X, 0L, xs_dev, 0L, (const double*)nullptr, 0L, (int)dp, (int)h->d, (int)n,
+      hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, st, h->X, 0L, xs_dev, 0L, (const double*)nullptr, 0L, (int)dp, (int)h->d, (int)n,
                          (int)n_pad, (int)mc, 0, h->scratchZ, 0L, ld, s.kps, 1);
       HIPCHK(h, hipGetLastError());
     }
     if ((rc = solve_rows_forward(h, s, h->scratchZ, n_pad))) return rc;
-    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(mc + 1), 1), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
+    hipLaunchKernelGGL(epilogue_kernel<double>, dim3((unsigned)(mc + 1), 1), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
                        (int)n_pad, (int)mc, s.res, 0L, 0L, 0L);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -950,6 +1175,14 @@ int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo) {
   if (which == SIGP_MAT_L && !h->factored) return fail(h, SIGP_BAD_ARG, "get_matrix: L~ is not resident");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
+  if (h->dtype == SIGP_F32) {
+    std::vector<float> tmp((size_t)h->n * h->n);
+    HIPCHK(h, hipMemcpy2D(tmp.data(), (size_t)h->n * sizeof(float), h->fmat, (size_t)h->n_pad * sizeof(float), (size_t)h->n * sizeof(float),
+                          (size_t)h->n, hipMemcpyDeviceToHost));
+    for (long i = 0; i < h->n; ++i)
+      for (long j = 0; j < h->n; ++j) out[i * ldo + j] = (j <= i) ? (double)tmp[(size_t)i * h->n + j] : 0.0;
+    return SIGP_OK;
+  }
   HIPCHK(h, hipMemcpy2D(out, (size_t)ldo * sizeof(double), s.mat, (size_t)h->n_pad * sizeof(double), (size_t)h->n * sizeof(double),
                         (size_t)h->n, hipMemcpyDeviceToHost));
   for (long i = 0; i < h->n; ++i)
@@ -1002,6 +1235,17 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
   if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..16");
   HIPCHK(h, hipSetDevice(h->device));
   const long n = h->b_n, d = h->b_d, dp = h->b_dp, m = h->b_m, n_pad = h->b_npad;
+  if (h->dtype == SIGP_F32) {   // fp32 engine: one fit at a time (factor + refinement), data sets resident in HBM
+    for (long i = 0; i < count; ++i) {
+      if (!(ell[i] > 0) || !(sn_tilde[i] >= 0)) return fail(h, SIGP_BAD_ARG, "batch_run: ell > 0 and sn_tilde >= 0 required");
+      const long ds = (first + i) % h->b_count;
+      int rc32 = f32_fit(h, kernel_id, ell[i], sn_tilde[i], h->bX + ds * n_pad * dp, h->by + ds * n_pad, h->bXs + ds * (long)RIDE * dp, n, d, dp,
+                         n_pad, m, out + 4 * i, mean ? mean + i * m : nullptr, var ? var + i * m : nullptr);
+      if (rc32) return rc32;
+    }
+    h->built = h->factored = h->fitted = false;
+    return SIGP_OK;
+  }
   // fits are factorised in lockstep groups of G (one launch covers the same step of G fits); `concurrency`
   // groups are in flight on separate stream pairs so one group's panel chain overlaps another's updates
   const int G = (int)std::max<long>(1, std::min<long>(h->opt_group, count));
@@ -1093,6 +1337,7 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   if (!h || !theta || !nlml || h->n == 0) return fail(h, SIGP_BAD_ARG, "nlml_grad: bad argument");
   if (grad_mode < 0 || grad_mode > 2) return fail(h, SIGP_BAD_ARG, "nlml_grad: grad_mode must be 0, 1 (reference formulae) or 2 (exact)");
   if (grad_mode != 0 && !grad) return fail(h, SIGP_BAD_ARG, "nlml_grad: grad buffer required");
+  if (grad_mode != 0 && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "nlml_grad: gradients need the fp64 engine");
   if (grad_mode == 1 && kernel_id != SIGP_KERNEL_NETDIFFUSION) return fail(h, SIGP_BAD_ARG, "nlml_grad: the reference gradient formulae exist for the reference kernel only");
   if (grad_mode != 0 && kernel_id == SIGP_KERNEL_NETDIFFUSION && !MSigma) return fail(h, SIGP_BAD_ARG, "nlml_grad: M @ Sigma~ required");
   const double inf = std::numeric_limits<double>::infinity();
@@ -1142,7 +1387,7 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
     s.kps_host[0] = make_kparams(kernel_id == SIGP_KERNEL_RBF ? KID_RBF_DLOGL : KID_MATERN52_DLOGL, ell, 0.0, 0);
     if ((rc = upload_kparams(h, s, 1))) return rc;
     dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), 1);
-    hipLaunchKernelGGL(kbuild_kernel, grid, dim3(256), 0, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
+    hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
     HIPCHK(h, hipGetLastError());
   }
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)n), dim3(256), 0, st, h->gK, h->gD, h->scratchZ, ld, (int)n, h->gPart);
@@ -1172,12 +1417,14 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
 int64_t sigp_num_blocks(sigp_handle* h) { return h ? h->n_pad / NB : 0; }
 
 int sigp_dist_begin(sigp_handle* h) {
+  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "dist_begin: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
+
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "dist_begin: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
   static bool diag_attr = false;
   if (!diag_attr) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
     diag_attr = true;
   }
   HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
@@ -1325,14 +1572,14 @@ int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps,
   HIPCHK(h, hipMemset(li, 0, NB * NB * 8));
   HIPCHK(h, hipMemcpy(a0, A128, NB * NB * 8, hipMemcpyHostToDevice));
   HIPCHK(h, hipMemset(info, 0, 4));
-  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   hipStream_t st = h->slots[0].s_upd;
   hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
   double tot = 0;
   for (int r = 0; r < reps + 2; ++r) {
     HIPCHK(h, hipMemcpyAsync(a1, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
     HIPCHK(h, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip, 0L, 0L);
+    hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip, 0L, 0L);
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
     float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
@@ -1399,7 +1646,8 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
     std::vector<unsigned long long> hs((size_t)ngrid * 2);
     HIPCHK(h, hipMemcpy(hs.data(), stamp, hs.size() * 8, hipMemcpyDeviceToHost));
     double sc = 0, sr = 0;
-    for (int i = 0; i < ngrid; ++i) { sc += (double)hs[2 * i]; sr += (double)hs[2 * i + 1]; }
+    for (int i = 0; i < ngrid; ++i) { sc += (double)hs[2 * i]; sr += (double)(hs[2 * i + 1] >> 8); }
+    if (dbg & 32) { fprintf(stderr, "[xcc by block]"); for (int i = 0; i < std::min(ngrid, 96); ++i) fprintf(stderr, " %d", (int)(hs[2 * i + 1] & 0xf)); fprintf(stderr, "\n"); }
     *clock_ghz = sr > 0 ? sc / (sr * 10.0) : 0.0;   // s_memrealtime ticks at 100 MHz
     (void)hipFree(stamp);
   }

@@ -31,13 +31,16 @@ class GPR:
     def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
-        if dtype != "f64":
-            raise NotImplementedError("dtype %r: only the fp64 engine is built (config 5's fp32 + refinement is not)" % dtype)
+        if dtype not in ("f64", "f32"):
+            raise ValueError("dtype must be 'f64' or 'f32'")
+        if dtype == "f32" and kernel == "netdiffusion":
+            raise ValueError("the fp32 engine (fp32 factor + fp64 iterative refinement) covers the RBF / Matern kernels only")
+        self.dtype = dtype
         self.kernel = kernel
         self._kid = L.KERNEL_IDS[kernel]
         self._lib = L.load()
         h = C.c_void_p()
-        rc = self._lib.sigp_create(C.byref(h), int(device), 0)
+        rc = self._lib.sigp_create(C.byref(h), int(device), 0 if dtype == "f64" else 1)
         if rc != L.OK:
             raise L.SigpError("sigp_create(device=%d) failed (rc=%d): no usable MI355X / HIP runtime; there is no CPU fallback"
                               % (device, rc))
@@ -112,7 +115,7 @@ class GPR:
         Xs = L.f64(np.atleast_2d(Xs), 2)
         if Xs.shape[1] != self.d:
             raise ValueError("Xs must have %d columns" % self.d)
-        if Xs.shape[0] > L.MAX_RIDE:
+        if Xs.shape[0] > (L.MAX_RIDE if self.dtype == "f64" else 3):
             self._ride = None      # too many to ride along: predict() takes the general path
             self._check(self._lib.sigp_set_test(self._h, None, 0, 0), "set_test")
             return

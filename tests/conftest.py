@@ -1,6 +1,11 @@
 import os
 import sys
 
+# the boxes report 256 logical CPUs but schedule far fewer: 64 spinning OpenBLAS threads on tiny matrices only add
+# latency (and are a suspect for a rare multi-minute stall); the oracle's matrices here are small
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "8")
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+
 import numpy as np
 import pytest
 

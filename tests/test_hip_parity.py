@@ -338,3 +338,41 @@ def test_sharded_cholesky_panel_broadcast(tmp_path, world):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     for r in range(world):
         assert (tmp_path / ("ok_%d" % r)).exists()
+
+
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+@pytest.mark.parametrize("n,d", [(300, 4), (1024, 8), (2049, 32)])
+def test_fp32_engine_with_fp64_refinement(S, kind, n, d):
+    """BASELINE configs[4] path (fp32 kernel matrix + Cholesky, fp64 iterative refinement with the covariance
+    recomputed on the fly) against the fp64 oracle.  Stated tolerances: mean, sigma_f, alpha <= 1e-6 relative
+    (SURVEY 8d), variance of the ride-along points <= 1e-5 (refined), nlML <= 1e-5 (its log-det comes from the fp32
+    factor), general-path variance <= 1e-3 (fp32 factor)."""
+    X, y, Xs = O.synthetic_problem(n, d, 77 + n, m=2)
+    ell, sn = np.sqrt(d), 1e-1
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    with S.GPR(kernel=kind, dtype="f32") as gp:
+        gp.fit(X, y, ell, sn, Xs=Xs)
+        mu, var = gp.predict(Xs)
+        assert rel(mu, ref["fmean"]) <= 1e-6 and rel(var, ref["fvar"]) <= 1e-5, (rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
+        assert rel(gp.sigma_f_, ref["sigma_f"]) <= 1e-6 and rel(gp.nlml_, ref["nlml"]) <= 1e-5
+        assert rel(gp.alpha_, ref["alpha"]) <= 1e-6
+        assert rel(gp.L_tilde_, ref["L_tilde"]) <= 1e-3            # the factor itself is fp32
+        Xs2 = np.random.default_rng(1).standard_normal((140, d))     # > 128 points: chunked general path
+        ref2 = O.fit_predict(X, y, Xs2, ell, sn, kind=kind, ref_idiom=False)
+        mu2, var2 = gp.predict(Xs2)
+        assert rel(mu2, ref2["fmean"]) <= 1e-6 and rel(var2, ref2["fvar"]) <= 1e-3
+    with pytest.raises(ValueError):
+        S.GPR(kernel="netdiffusion", dtype="f32")
+
+
+def test_fp32_batch_and_not_spd(S):
+    n, d = 700, 8
+    X, y, Xs = O.synthetic_problem(n, d, 31, m=1)
+    with S.GPR(kernel="matern52", dtype="f32") as gp:
+        r = gp.fit_batch(X, y, Xs, [2.0, 3.0, 2.5], [1e-1, 1e-1, 2e-1], concurrency=1, group=4)
+        for i, (e, s_) in enumerate(zip([2.0, 3.0, 2.5], [1e-1, 1e-1, 2e-1])):
+            ref = O.fit_predict(X, y, Xs, e, s_, kind="matern52", ref_idiom=False)
+            assert rel(r["mean"][i], ref["fmean"]) <= 1e-6 and rel(r["nlml"][i], ref["nlml"]) <= 1e-5
+        Xbad = X.copy(); Xbad[300:360] = Xbad[0:60]
+        with pytest.raises(np.linalg.LinAlgError):
+            gp.fit(Xbad, y, 2.0, 0.0)
