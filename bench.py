@@ -53,13 +53,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     dist = None
+    backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
+    local = local % torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from oracle import gp_oracle as O                       # synthetic generator + cpu_baseline leg only
     from seaiceextentforecasting_amd import GPR
@@ -102,7 +107,7 @@ def main():
     gp.profile(False)
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert np.all(r["info"] == 0) and np.all(np.isfinite(r["mean"]))
@@ -128,6 +133,16 @@ def main():
                                "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS,
                                "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch": dom["flops"] / dom["launches"]}
+            # HBM-side traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot
+            # share a pass, and PMC collection serialises kernels), summarised under profiles/ by tools/collect_profiles.sh
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_syrk128.json")))
+                if n == 8192 and d == 8 and args.group == 16 and args.outer == 8:
+                    out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_pmc_syrk128.json)"
+                    out["roofline"]["algorithmic_c_bytes_per_launch"] = dom["bytes"] / dom["launches"]
+            except Exception:
+                pass
         else:
             out["roofline"] = None
         kb = prof["kbuild"]
@@ -153,6 +168,11 @@ def main():
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
                                "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d)" % (nb, d, np.__version__, ncpu, os.cpu_count()),
                                "seconds": tc}
+        t0 = time.perf_counter()
+        O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=False)
+        tb = time.perf_counter() - t0
+        out["cpu_baseline_best_practice"] = {"value": 1.0 / tb, "unit": "fits/s", "cores": ncpu, "kind": "port", "seconds": tb,
+                                             "sample": "1 fit, same inputs, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)"}
         if nb == n:   # parity of the timed configuration against the CPU path on the same inputs
             with GPR(kernel="rbf", device=local) as g2:
                 g2.fit(Xc, yc, grid_point(0, d)[0], grid_point(0, d)[1], Xs=Xsc)
