@@ -7,6 +7,7 @@ from .gpr import GPR, LinAlgError  # noqa: F401
 from .features import (SCRIPT_TABLE, LGRID, SGRID, select_features, design_matrix, laplacian_M,  # noqa: F401
                        sigma_tilde)
 from .retro import retro_forecast, operational_forecast  # noqa: F401
+from .callers import detrend, detrend_cube, skill, forecast_tables  # noqa: F401
 from .dist import shard_indices, gather_results, fit_batch_sharded, DistributedGPR  # noqa: F401
 
 __all__ = ["GPR", "LinAlgError", "SCRIPT_TABLE", "LGRID", "SGRID", "select_features", "design_matrix",

@@ -1,0 +1,82 @@
+"""The callers immediately before and after the GP block, restated with the reference's
+outputs: per-pixel linear detrending (the step before the ComplexNetworks feature pipeline) and the retro
+``skill()`` scores + the two CSV tables.  Host-side NumPy: these are O(pixels x years) / O(years) and feed or
+consume the HIP engine; parity is pinned by tests/golden/callers.npz (the reference's own functions run on
+synthetic inputs)."""
+import numpy as np
+
+
+def detrend_cube(data):
+    """Per-pixel least-squares line removal over the last axis, all pixels at once.
+
+    Restates ``detrend`` (north/June1st.py:179-194): pixels that are all-NaN stay NaN; a pixel with some NaN
+    gets NaN slope/intercept (``scipy.stats.linregress`` propagates NaN), hence an all-NaN detrended series.
+    Returns (detrended [X,Y,T], trend [X,Y,2] = slope, intercept)."""
+    data = np.asarray(data, dtype=np.float64)
+    X, Y, T = data.shape
+    t = np.arange(T, dtype=np.float64)
+    tm = t.mean()
+    ssxm = np.mean((t - tm) ** 2)
+    ym = data.mean(axis=2)                                   # NaN wherever a pixel has any NaN
+    ssxym = np.mean((t - tm) * (data - ym[:, :, None]), axis=2)
+    slope = ssxym / ssxm
+    intercept = ym - slope * tm
+    allnan = np.isnan(data).all(axis=2)
+    slope = np.where(allnan, np.nan, slope)
+    intercept = np.where(allnan, np.nan, intercept)
+    detrended = data - (slope[:, :, None] * t + intercept[:, :, None])
+    return detrended, np.stack([slope, intercept], axis=2)
+
+
+def detrend(dataset, fmin=None, fmax=None):
+    """In-place drop-in for the reference's ``detrend``: operational form ``detrend(dataset)`` sets
+    ``dataset['dt'], dataset['trend']`` (north/June1st.py:179-194); retro form ``detrend(dataset, fmin, fmax)``
+    sets ``dataset['dt_YYYY'], dataset['trend_YYYY']`` from the first YYYY-1979+1 years
+    (north/retrospective_forecasts/June1st_retro.py:178-195)."""
+    if fmin is None:
+        dataset["dt"], dataset["trend"] = detrend_cube(dataset["data"])
+        return dataset
+    for year in range(fmin, fmax + 1):
+        n = year - 1979 + 1
+        dataset["dt_%d" % year], dataset["trend_%d" % year] = detrend_cube(dataset["data"][:, :, :n])
+    return dataset
+
+
+def skill(GPR, SIEs, SIEs_dt, fmin, fmax, regions):
+    """MSE skill scores ``1 - MSE/MSE_clim`` of the retrended and detrended forecasts, rounded to 3 decimals
+    (north/retrospective_forecasts/June1st_retro.py:293-314).  Returns (skill_rt, skill_dt, dt_obs)."""
+    skill_rt, skill_dt, dt_obs = [], [], []
+    for region in regions:
+        dt = [SIEs_dt[region][t - (fmin - 1), t - 1979] for t in range(fmin, fmax + 1)]
+        dt_obs.append(dt)
+        obs_rt = np.asarray(SIEs[region])[fmin - 1979:]
+        a = np.mean((obs_rt - GPR[region + "_fmean_rt"]) ** 2)
+        b = np.mean((obs_rt - np.nanmean(obs_rt)) ** 2)
+        skill_rt.append((1 - (a / b)).round(3))
+        c = np.mean((np.asarray(dt) - GPR[region + "_fmean"]) ** 2)
+        d = np.mean((np.asarray(dt) - np.nanmean(dt)) ** 2)
+        skill_dt.append((1 - (c / d)).round(3))
+    return skill_rt, skill_dt, dt_obs
+
+
+def forecast_tables(GPR, SIEs, SIEs_dt, fmin, fmax, regions):
+    """The two DataFrames the retro scripts write as CSV (June1st_retro.py:346-369): detrended forecasts with
+    uncertainty (sqrt(fvar).round(3)) and forecasts with trend, one row per year plus a final 'Skill' row."""
+    import pandas as pd
+    skill_rt, skill_dt, dt_obs = skill(GPR, SIEs, SIEs_dt, fmin, fmax, regions)
+    years = list(range(fmin, fmax + 1)) + ["Skill"]
+
+    def prep(data, sk=None):
+        data = list(np.asarray(data).tolist())
+        data.append("" if sk is None else sk)
+        return data
+
+    cols_dt, cols_rt, data_dt, data_rt = [], [], [], []
+    for k, r in enumerate(regions):
+        cols_dt += [r + "$_o$", r + "$_f$", r + "$_f$ unc"]
+        data_dt += [prep(dt_obs[k]), prep(GPR[r + "_fmean"], skill_dt[k]), prep(np.sqrt(GPR[r + "_fvar"]).round(3))]
+        cols_rt += [r + "$_o$", r + "$_f$"]
+        data_rt += [prep(np.asarray(SIEs[r])[fmin - 1979:]), prep(GPR[r + "_fmean_rt"], skill_rt[k])]
+    df_dt = pd.DataFrame(list(zip(*data_dt)), index=years, columns=cols_dt)
+    df_rt = pd.DataFrame(list(zip(*data_rt)), index=years, columns=cols_rt)
+    return df_dt, df_rt

@@ -113,7 +113,9 @@ __device__ inline bool gemm_tile_coords(const GemmArgsT<T>& g, int b, int& bi, i
   }
   // lower, patched: rows effectively start at the column (r0 <= c0 for every caller)
   const int PATCH = g.patch;
-  const int xcd = b & 7, s = b >> 3;
+  // rotate the patch -> XCC assignment per batch member so that half-empty diagonal patches do not always land on
+  // the same XCC
+  const int xcd = (b + (int)blockIdx.y) & 7, s = b >> 3;
   int P = (s / (PATCH * PATCH)) * 8 + xcd;
   const int w = s % (PATCH * PATCH);
   const int prmax = (g.r1 - g.c0 + PATCH - 1) / PATCH, pcn = (g.c1 - g.c0 + PATCH - 1) / PATCH;

@@ -102,12 +102,14 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
     __builtin_amdgcn_sched_barrier(0);
+    if (g.dbg & 64) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
+    if (g.dbg & 64) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (!(g.dbg & 4)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);

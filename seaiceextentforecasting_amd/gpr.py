@@ -214,6 +214,26 @@ class GPR:
         self._check(rc, "nlml")
         return np.float64(val.value), (None if grad is None else g)
 
+    def optimize(self, theta0, method="L-BFGS-B", grad="exact", **kw):
+        """The reference's commented-out optimiser call (north/June1st.py:259-262:
+        ``minimize(MLII, x0=[log l0, log sn0], method='CG', jac=True)``) against the device engine.
+        ``grad='exact'`` (default) feeds the true derivative of the profiled nlML; ``grad='ref'`` reproduces the
+        reference's MLII contract verbatim (its "gradient" is not the derivative, so CG stalls as in SURVEY App. C-7).
+        Returns the scipy ``OptimizeResult``; afterwards the handle is fitted at ``exp(result.x)``."""
+        from scipy.optimize import minimize
+
+        def fun(th):
+            v, g = self.nlml(th, grad=grad)
+            return float(v), np.asarray(g, dtype=np.float64)
+
+        res = minimize(fun, np.asarray(theta0, dtype=np.float64), method=method, jac=True, **kw)
+        if np.all(np.isfinite(res.x)):
+            try:
+                self.refit(float(np.exp(res.x[0])), float(np.exp(res.x[1])))
+            except LinAlgError:
+                pass
+        return res
+
     # ---- state accessors -----------------------------------------------------------------------
     @property
     def alpha_(self):

@@ -376,3 +376,19 @@ def test_fp32_batch_and_not_spd(S):
         Xbad = X.copy(); Xbad[300:360] = Xbad[0:60]
         with pytest.raises(np.linalg.LinAlgError):
             gp.fit(Xbad, y, 2.0, 0.0)
+
+
+def test_optimiser_loop_on_the_device_engine(S):
+    """The reference's commented-out minimize(MLII, ...) call (north/June1st.py:259-262) re-enabled against the
+    engine with the exact gradient: the optimum has a (numerically) zero gradient and a lower nlML than the start."""
+    X, y, _ = O.synthetic_problem(400, 4, 5, m=1)
+    th0 = np.array([np.log(1.0), np.log(0.5)])
+    with S.GPR(kernel="rbf") as gp:
+        gp.set_data(X, y)
+        f0, _ = gp.nlml(th0, grad=None)
+        res = gp.optimize(th0, method="L-BFGS-B")
+        f1, g1 = gp.nlml(res.x, grad="exact")
+        assert res.fun < f0 - 1.0 and abs(f1 - res.fun) <= 1e-9 * abs(f1)
+        assert np.max(np.abs(g1)) <= 1e-3 * max(1.0, abs(f1))
+        fo, go = O.mlii(res.x, X, y, kind="rbf", grad="exact")
+        assert abs(f1 - fo) <= 1e-9 * abs(fo)

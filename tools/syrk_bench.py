@@ -16,9 +16,9 @@ for seed in (0.25, -1.0):
 mode = sys.argv[1] if len(sys.argv) > 1 else "ablate"
 if mode == "ablate":
     print("rt   K small dbg |    ms   TFLOP/s")
-    for rt, K in ((62, 256), (62, 512), (62, 1024), (62, 2048), (32, 512)):
+    for rt, K in ((62, 1024), (62, 2048)):
         for small in (2,):
-            for dbg in (0, 1):
+            for dbg in (0, 64, 0, 64):
                 lib.sigp_debug_time_syrk(h, rt, K, 0, small, 5, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
                 print("%2d %4d %5d %3d | %6.3f  %6.1f   in-kernel clock %.2f GHz" % (rt, K, small, dbg, ms.value, tf.value, ghz.value))
 else:
