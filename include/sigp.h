@@ -134,7 +134,8 @@ int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_
 
 /* measurement ---------------------------------------------------------------------------------- */
 /* enable=1: bracket every kernel launch with HIP events on the stream it is launched on and
- * accumulate per kernel class; enable=0: off (default).  sigp_profile_get drains finished events. */
+ * accumulate per kernel class; enable = bit mask with bit (8+k) set: only kernel class k (less perturbation);
+ * enable=0: off (default).  sigp_profile_get drains finished events. */
 int sigp_profile(sigp_handle* h, int enable);
 int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* launches, double* flops,
                      double* bytes);

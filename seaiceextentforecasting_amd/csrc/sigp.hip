@@ -98,9 +98,9 @@ struct sigp_handle {
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
   int opt_host_timing = 0;   // print host enqueue time per batch_run (debug)
-  int opt_reserve_cus = 2;   // CUs masked out of the update streams so the panel chain always finds a free CU
+  int opt_reserve_cus = 0;   // CUs masked out of the update streams (0: none -- the 84 KB diagonal kernel fits beside an update workgroup, and a CU-masked stream measured 6 % slower)
   // profiling
-  bool prof = false;
+  unsigned prof = 0;         // bit k set: bracket launches of kernel class k with HIP events
   std::vector<ProfEvent> pev;
   double p_ms[SIGP_KC_COUNT] = {0};
   int64_t p_n[SIGP_KC_COUNT] = {0};
@@ -221,7 +221,7 @@ void slot_free(Slot& s) {
 // ---- profiling brackets -------------------------------------------------------------------------
 struct ProfScope {
   sigp_handle* h; hipStream_t st; ProfEvent pe; bool on;
-  ProfScope(sigp_handle* h_, hipStream_t st_, int kclass, double flops, double bytes, int K = 0) : h(h_), st(st_), on(h_->prof) {
+  ProfScope(sigp_handle* h_, hipStream_t st_, int kclass, double flops, double bytes, int K = 0) : h(h_), st(st_), on((h_->prof >> kclass) & 1u) {
     h->p_flops[kclass] += flops; h->p_bytes[kclass] += bytes; h->p_n[kclass] += 1;
     if (on) {
       pe.kclass = kclass; pe.flops = flops; pe.K = K;
@@ -1505,7 +1505,8 @@ int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, do
 int sigp_profile(sigp_handle* h, int enable) {
   if (!h) return SIGP_BAD_ARG;
   if (!enable) prof_drain(h);
-  h->prof = enable != 0;
+  // enable = 1: every class; otherwise a bit mask (bit k+8 = class k), e.g. (1 << (8 + SIGP_KC_SYRK128))
+  h->prof = enable == 0 ? 0u : enable == 1 ? 0xffu : ((unsigned)enable >> 8) & 0xffu;
   return SIGP_OK;
 }
 

@@ -331,8 +331,14 @@ class GPR:
         return r["nlml"].reshape(len(ells), len(sns))
 
     # ---- measurement ---------------------------------------------------------------------------
-    def profile(self, enable=True):
-        self._check(self._lib.sigp_profile(self._h, int(bool(enable))), "profile")
+    def profile(self, enable=True, classes=None):
+        """Bracket kernel launches with HIP events (all classes, or only the named ones, e.g. ["syrk128"])."""
+        code = int(bool(enable))
+        if enable and classes:
+            code = 0
+            for c in classes:
+                code |= 1 << (8 + L.KCLASS[c])
+        self._check(self._lib.sigp_profile(self._h, code), "profile")
 
     def profile_reset(self):
         self._check(self._lib.sigp_profile_reset(self._h), "profile_reset")
