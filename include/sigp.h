@@ -100,6 +100,8 @@ int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X
  * the timed region of bench.py starts here. */
 int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t strideX, const double* y,
                       int64_t stridey, const double* Xs, int64_t strideXs, int64_t n, int64_t d, int64_t m);
+/* allocate the lockstep slots for (group, concurrency) ahead of time, so no allocation falls inside a timed batch_run */
+int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency);
 int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* ell,
                    const double* sn_tilde, int concurrency, double* out, double* mean, double* var);
 

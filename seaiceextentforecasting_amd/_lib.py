@@ -36,6 +36,7 @@ SIGNATURES = {
     "sigp_fit_batch": (C.c_int, [_h, _i64, C.c_int, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64, _dp, _dp,
                                  C.c_int, _dp, _dp, _dp]),
     "sigp_batch_upload": (C.c_int, [_h, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64]),
+    "sigp_batch_reserve": (C.c_int, [_h, _i64, C.c_int]),
     "sigp_batch_run": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),

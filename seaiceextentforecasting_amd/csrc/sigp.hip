@@ -1228,6 +1228,18 @@ int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t st
   return SIGP_OK;
 }
 
+int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency) {
+  if (!h || h->b_count == 0 || group < 1 || group > 64 || concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_reserve: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (h->dtype == SIGP_F32) return f32_reserve(h, h->b_npad);
+  for (int k = 0; k < concurrency; ++k) {
+    int rc = slot_reserve(h, h->slots[k], h->b_npad, (int)group);
+    if (rc) return rc;
+  }
+  h->nslots = std::max(h->nslots, concurrency);
+  return SIGP_OK;
+}
+
 int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* ell, const double* sn_tilde,
                    int concurrency, double* out, double* mean, double* var) {
   if (!h || h->b_count == 0 || first < 0 || count < 1 || !ell || !sn_tilde || !out) return fail(h, SIGP_BAD_ARG, "batch_run: bad argument");

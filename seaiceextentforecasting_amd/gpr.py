@@ -302,6 +302,21 @@ class GPR:
         self._batch_m = m
         return self.run_batch(0, F, ell, sn, concurrency, group)
 
+    def upload_batch(self, X, y, Xs, group=8, concurrency=1):
+        """Stage data sets in HBM and allocate the lockstep slots without running any fit (bench warm-up)."""
+        X = L.f64(X)
+        Xb = X[None] if X.ndim == 2 else X
+        B, n, d = Xb.shape
+        yb = L.f64(np.asarray(y).reshape(B, n))
+        m, Xsb = 0, None
+        if Xs is not None:
+            Xsb = L.f64(Xs)
+            Xsb = Xsb[None] if Xsb.ndim == 2 else Xsb
+            m = Xsb.shape[1]
+        self._check(self._lib.sigp_batch_upload(self._h, B, L.ptr(Xb), n * d, L.ptr(yb), n, L.ptr(Xsb), m * d, n, d, m), "batch_upload")
+        self._batch_m = m
+        self._check(self._lib.sigp_batch_reserve(self._h, int(group), int(concurrency)), "batch_reserve")
+
     def run_batch(self, first, count, ell, sn_tilde, concurrency=2, group=8):
         """Run ``count`` fits on the data sets already resident in HBM (after fit_batch / upload).
         ``group`` fits are factorised in lockstep by each launch; ``concurrency`` groups are in flight."""

@@ -392,3 +392,33 @@ def test_optimiser_loop_on_the_device_engine(S):
         assert np.max(np.abs(g1)) <= 1e-3 * max(1.0, abs(f1))
         fo, go = O.mlii(res.x, X, y, kind="rbf", grad="exact")
         assert abs(f1 - fo) <= 1e-9 * abs(fo)
+
+
+def test_one_handle_through_changing_sizes_kernels_and_paths(S):
+    """State hygiene: one handle reused across sizes (buffers grow and shrink logically), ride / no-ride fits,
+    batch runs in between, general predict and alpha after each -- every result against the oracle."""
+    rng = np.random.default_rng(2024)
+    with S.GPR(kernel="matern52") as gp:
+        for step, n in enumerate([300, 1100, 64, 515, 129, 1100]):
+            d = 5
+            X, y, Xs = O.synthetic_problem(n, d, 900 + step, m=2)
+            ell, sn = float(1.5 + rng.random()), float(10 ** rng.uniform(-2.5, -1))
+            ref = O.fit_predict(X, y, Xs, ell, sn, kind="matern52", ref_idiom=False)
+            if step % 2 == 0:
+                gp.fit(X, y, ell, sn, Xs=Xs)
+            else:
+                gp.fit(X, y, ell, sn)                      # no ride rows: predict takes the general path
+            mu, var = gp.predict(Xs)
+            assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= TOL_PRED, (step, n)
+            assert rel(gp.alpha_, ref["alpha"]) <= 1e-8 and rel(gp.nlml_, ref["nlml"]) <= 1e-9
+            if step in (1, 3):                              # a batch run clobbers the single-fit slot
+                r = gp.fit_batch(X, y, Xs, [ell, 2 * ell], [sn, sn], concurrency=2, group=2)
+                assert rel(r["mean"][0], ref["fmean"]) <= TOL_PRED
+                with pytest.raises(RuntimeError):
+                    gp.predict(Xs)                          # no fitted state after a batch
+                gp.refit(ell, sn)
+                mu2, _ = gp.predict(Xs)
+                assert rel(mu2, ref["fmean"]) <= TOL_PRED
+            f, g = gp.nlml(np.log([ell, sn]), grad="exact")
+            fo, go = O.mlii(np.log([ell, sn]), X, y, kind="matern52", grad="exact")
+            assert abs(f - fo) <= 1e-9 * abs(fo) and np.allclose(g, go, rtol=1e-6, atol=1e-8), (step, g, go)
