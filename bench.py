@@ -138,7 +138,7 @@ def main():
         dom = prof["syrk128"]
         if dom["launches"] and dom["ms"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            out["roofline"] = {"bound": "mfma", "kernel": "gemm_mfma_kernel (outer trailing update, C -= A B^T)",
+            out["roofline"] = {"bound": "mfma", "kernel": "sigp::syrk128_kernel<double,false> (inner + trailing updates C -= P P^T, fp64 v_mfma_f64_16x16x4_f64)",
                                "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS,
                                "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch": dom["flops"] / dom["launches"]}
