@@ -48,7 +48,8 @@ def load_golden(name):
     return g
 
 
-GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "callers.npz")
+GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN)
+                      if f.endswith(".npz") and f != "callers.npz" and not f.startswith("networks_"))
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

@@ -188,3 +188,45 @@ def test_detrend_matches_reference():
     ds2 = S.detrend({"data": data.copy()})
     assert np.array_equal(np.isnan(ds2["dt"]), np.isnan(z["detrend_op/dt"]))
     assert np.nanmax(np.abs(ds2["dt"] - z["detrend_op/dt"])) <= 1e-12 and np.nanmax(np.abs(ds2["trend"] - z["detrend_op/trend"])) <= 1e-12
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c", "d"])
+def test_complex_networks_restatement_matches_reference(case):
+    """networks.Network == ComplexNetworks.Network (reference module run on synthetic fields, goldens
+    tests/golden/networks_*.npz): tau, the areas V (same ids, same cells in the same order), the anomaly series that
+    become the GP's features, links, strength map."""
+    import seaiceextentforecasting_amd.networks as NW
+    z = np.load(os.path.join(ROOT, "tests", "golden", "networks_%s.npz" % case), allow_pickle=False)
+    data, aux, latlon = z["data"], z["aux"], bool(int(z["latlon"]))
+    net = NW.Network(data=data.copy())
+    NW.Network.tau(net, 0.01)
+    assert net.tau == float(z["tau"])
+    NW.Network.area_level(net, latlon_grid=latlon)
+    ids = [int(i) for i in z["area_ids"]]
+    assert list(net.V.keys()) == ids
+    for k in ids:
+        assert np.array_equal(np.array(net.V[k], dtype=np.int64), z["V/%d" % k]), k
+    if latlon:
+        NW.Network.intra_links(net, lat=aux)
+    else:
+        NW.Network.intra_links(net, area=aux)
+    for k in ids:
+        assert np.array_equal(net.anomaly[k], z["anomaly/%d" % k])
+        assert np.allclose(net.links[k], z["links/%d" % k], rtol=1e-13, atol=1e-13)
+        assert abs(net.strength[k] - float(z["strength/%d" % k])) <= 1e-12 * abs(float(z["strength/%d" % k]))
+    assert np.array_equal(np.isnan(net.strengthmap), np.isnan(z["strengthmap"]))
+
+
+def test_networks_driver_feeds_the_feature_rules():
+    """networks() -> dataset['anoms'] has the contract features.select_features consumes (dict id -> series of length T)."""
+    import seaiceextentforecasting_amd as S
+    import seaiceextentforecasting_amd.networks as NW
+    z = np.load(os.path.join(ROOT, "tests", "golden", "networks_a.npz"), allow_pickle=False)
+    ds = {"dt": z["data"].copy(), "psar": z["aux"]}
+    NW.networks(ds, latlon=False)
+    T = z["data"].shape[2]
+    assert all(v.shape == (T,) for v in ds["anoms"].values())
+    y = np.random.default_rng(0).standard_normal((T - 1, 1))
+    feats = S.select_features(y, ds["anoms"], rule="all_then_pos_p", k=0, pthr=0.05)
+    X, Xs = S.design_matrix(feats, False)
+    assert X.shape == (T - 1, len(ds["anoms"])) and Xs.shape == (1, len(ds["anoms"]))
