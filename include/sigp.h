@@ -130,6 +130,14 @@ int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf);  
 int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf); /* buf -> matrix + dinv  */
 /* trailing update of column blocks [J+W+c0, J+W+c1) with panel J..J+W (only the caller's own panels) */
 int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1);
+/* Look-ahead support: with sigp_set_option(h, "dist_async", 1) sigp_dist_update and sigp_dist_panel_unpack only
+ * enqueue their work (unpack on the panel stream, the update stream waits for it) and return; sigp_dist_sync
+ * blocks until the received panels are unpacked (which = 1: the broadcast buffer may be reused) or until all
+ * enqueued work is done (which = 0).  In that mode sigp_dist_panel_factor / _pack run on the panel stream: the
+ * factor starts once the update-stream work enqueued before the last sigp_dist_mark is done (the update of that
+ * panel's own columns) and overlaps the updates enqueued after the mark; both still return synchronously. */
+int sigp_dist_sync(sigp_handle* h, int which);
+int sigp_dist_mark(sigp_handle* h);
 /* after the last panel: reductions + results, as sigp_fit_predict's out/mean/var; marks the handle fitted */
 int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var);
 int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_pad / 128                        */

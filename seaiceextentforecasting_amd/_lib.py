@@ -47,6 +47,8 @@ SIGNATURES = {
     "sigp_dist_panel_pack": (C.c_int, [_h, _i64, _i64, C.c_void_p]),
     "sigp_dist_panel_unpack": (C.c_int, [_h, _i64, _i64, C.c_void_p]),
     "sigp_dist_update": (C.c_int, [_h, _i64, _i64, _i64, _i64]),
+    "sigp_dist_sync": (C.c_int, [_h, C.c_int]),
+    "sigp_dist_mark": (C.c_int, [_h]),
     "sigp_dist_finish": (C.c_int, [_h, _i64, _dp, _dp, _dp]),
     "sigp_num_blocks": (_i64, [_h]),
     "sigp_profile": (C.c_int, [_h, C.c_int]),

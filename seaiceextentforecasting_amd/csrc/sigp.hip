@@ -93,6 +93,7 @@ struct sigp_handle {
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
   int opt_pan_priority = 1;  // panel streams at high priority
   int opt_panel_ll = 0;      // panels up to this width are factored left-looking (0 = binary recursion only)
+  int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
@@ -453,7 +454,7 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
 }
 
 // stand-alone pieces of potrf_slot for the multi-GPU driver (one member, slot stream, no look-ahead)
-int dist_update(sigp_handle* h, Slot& s, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
+int dist_update(sigp_handle* h, Slot& s, hipStream_t st, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB), R = T + 1;
   const long o = (long)ccol0 * NB;
@@ -463,13 +464,12 @@ int dist_update(sigp_handle* h, Slot& s, long n_pad, int kcol0, int kw, int ccol
   g.C = s.mat + o * ld + o; g.ldc = ld;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
   g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = 0;
-  return gemm_sub_auto(h, s.s_upd, g);
+  return gemm_sub_auto(h, st, g);
 }
 
-int dist_panel(sigp_handle* h, Slot& s, long n_pad, int J0, int Wp) {
+int dist_panel(sigp_handle* h, Slot& s, hipStream_t sp, long n_pad, int J0, int Wp) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB), R = T + 1;
-  hipStream_t sp = s.s_upd;
   if (Wp == 1) {
     const int c = J0;
     hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, s.mat + (long)c * NB * ld + (long)c * NB, ld,
@@ -485,10 +485,10 @@ int dist_panel(sigp_handle* h, Slot& s, long n_pad, int J0, int Wp) {
     return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   }
   const int hw = Wp / 2;
-  int rc = dist_panel(h, s, n_pad, J0, hw);
+  int rc = dist_panel(h, s, sp, n_pad, J0, hw);
   if (rc) return rc;
-  if ((rc = dist_update(h, s, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
-  return dist_panel(h, s, n_pad, J0 + hw, Wp - hw);
+  if ((rc = dist_update(h, s, sp, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
+  return dist_panel(h, s, sp, n_pad, J0 + hw, Wp - hw);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
@@ -772,6 +772,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     return SIGP_OK;
   }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
@@ -1457,11 +1458,27 @@ int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info) 
   if (!dist_args_ok(h, J, W)) return fail(h, SIGP_BAD_ARG, "dist_panel_factor: bad panel");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = dist_panel(h, s, h->n_pad, (int)J, (int)W);
+  // look-ahead mode: the panel is factored on the panel stream, after the update-stream work enqueued up to the
+  // last sigp_dist_mark (the update of this panel's columns), concurrently with the updates enqueued after the
+  // mark; later update-stream work waits for the factor
+  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
+  if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
+  int rc = dist_panel(h, s, sp, h->n_pad, (int)J, (int)W);
   if (rc) return rc;
-  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
-  if ((rc = sync_slot(h, s))) return rc;
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
+  if (h->opt_dist_async) {
+    HIPCHK(h, hipEventRecord(s.ev_pan, sp));
+    HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
+  }
+  HIPCHK(h, hipStreamSynchronize(sp));
   if (info) *info = *s.info_host;
+  return SIGP_OK;
+}
+
+int sigp_dist_mark(sigp_handle* h) {
+  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_mark: no fit in progress");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->slots[0].ev_la, h->slots[0].s_upd));
   return SIGP_OK;
 }
 
@@ -1469,12 +1486,14 @@ int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf) {
   if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_pack: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
+  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;      // same stream as the factor that produced the panel
   const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
   double* buf = (double*)dev_buf;
   HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * 8, s.mat + J * NB * ld + J * NB, (size_t)ld * 8, (size_t)wcols * 8, (size_t)rows,
-                             hipMemcpyDeviceToDevice, s.s_upd));
-  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, s.dinv + J * NB * NB, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_upd));
-  return sync_slot(h, s);
+                             hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, s.dinv + J * NB * NB, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, hipStreamSynchronize(sp));
+  return SIGP_OK;
 }
 
 int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf) {
@@ -1483,19 +1502,35 @@ int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev
   Slot& s = h->slots[0];
   const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
   const double* buf = (const double*)dev_buf;
+  // the copy runs on the panel stream: a rank never updates columns it does not own, so a received panel can land
+  // while the update stream is still busy with the previous panel's updates; the update stream waits for it
   HIPCHK(h, hipMemcpy2DAsync(s.mat + J * NB * ld + J * NB, (size_t)ld * 8, buf, (size_t)wcols * 8, (size_t)wcols * 8, (size_t)rows,
-                             hipMemcpyDeviceToDevice, s.s_upd));
-  HIPCHK(h, hipMemcpyAsync(s.dinv + J * NB * NB, buf + rows * wcols, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_upd));
-  return sync_slot(h, s);
+                             hipMemcpyDeviceToDevice, s.s_pan));
+  HIPCHK(h, hipMemcpyAsync(s.dinv + J * NB * NB, buf + rows * wcols, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_pan));
+  HIPCHK(h, hipEventRecord(s.ev_pan, s.s_pan));
+  HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
+  if (h->opt_dist_async) return SIGP_OK;
+  HIPCHK(h, hipStreamSynchronize(s.s_pan));
+  return SIGP_OK;
 }
 
 int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1) {
   if (!dist_args_ok(h, J, W) || c0 < 0 || c1 < c0 || J + W + c1 > h->n_pad / NB) return fail(h, SIGP_BAD_ARG, "dist_update: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = dist_update(h, s, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
+  int rc = dist_update(h, s, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
   if (rc) return rc;
+  if (h->opt_dist_async) return SIGP_OK;
   return sync_slot(h, s);
+}
+
+int sigp_dist_sync(sigp_handle* h, int which) {
+  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_sync: no fit in progress");
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  HIPCHK(h, hipStreamSynchronize(s.s_pan));
+  if (which == 0) HIPCHK(h, hipStreamSynchronize(s.s_upd));
+  return SIGP_OK;
 }
 
 int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var) {

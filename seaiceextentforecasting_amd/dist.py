@@ -75,15 +75,16 @@ class DistributedGPR:
 
     Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277)."""
 
-    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4):
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True):
         from .gpr import GPR
         import torch
         self._torch = torch
         self.rank, self.world, self.dist = int(rank), int(world), dist
         self.W = int(outer_blocks)
+        self.lookahead = bool(lookahead)
         self.gp = GPR(kernel=kernel, device=device)
         self.device = device
-        self._buf = None
+        self._bufs = [None, None]
 
     def close(self):
         self.gp.close()
@@ -98,40 +99,92 @@ class DistributedGPR:
         return panel_index % self.world
 
     def fit(self, X, y, ell, sn_tilde, M=None, Xs=None):
+        """With ``lookahead`` (default) the owner of panel p+1 updates that panel's columns first, factors it and
+        starts its broadcast while every rank is still applying panel p to the rest of its columns, so the xGMI
+        transfer and the owner's latency chain hide behind the trailing update.  Without it the steps
+        run strictly one after the other.  Both orders do the same arithmetic: results are bit-identical."""
         from . import _lib as L
         from .gpr import LinAlgError
         torch, gp, lib = self._torch, self.gp, self.gp._lib
         gp.set_data(X, y, M=M, Xs=Xs)          # X, y replicated on every rank (n*d*8 bytes)
         gp.build(ell, sn_tilde)                # every rank builds K~; it only ever updates the panels it owns
         gp._check(lib.sigp_dist_begin(gp._h), "dist_begin")
+        gp.set_option("dist_async", 1 if self.lookahead else 0)
         T = int(lib.sigp_num_blocks(gp._h))
         panels = [(J, min(self.W, T - J)) for J in range(0, T, self.W)]
-        nmax = max(int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels) + 1
-        if self._buf is None or self._buf.numel() < nmax:
-            self._buf = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
+        P = len(panels)
+        nelem = [int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels]
+        nmax = max(nelem) + 1
+        for k in range(2):                     # two broadcast buffers: panel p+1 is received while panel p is in use
+            if self._bufs[k] is None or self._bufs[k].numel() < nmax:
+                self._bufs[k] = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
+
+        def view(p):
+            return self._bufs[p % 2][:nelem[p] + 1]
+
+        def factor_and_pack(p):                # owner: panel p is up to date -> factor, pack [panel | dinv | info]
+            J, Wc = panels[p]
+            pinfo = C.c_int64(0)
+            gp._check(lib.sigp_dist_panel_factor(gp._h, J, Wc, C.byref(pinfo)), "dist_panel_factor")
+            gp._check(lib.sigp_dist_sync(gp._h, 1), "dist_sync")          # the buffer's previous panel is unpacked
+            gp._check(lib.sigp_dist_panel_pack(gp._h, J, Wc, C.c_void_p(view(p).data_ptr())), "dist_panel_pack")
+            view(p)[nelem[p]] = float(pinfo.value)
+
+        def start_bcast(p):                    # the block-row panel broadcast (RCCL over xGMI with backend "nccl")
+            if self.world == 1:
+                return None
+            return self.dist.broadcast(view(p), src=self.owner(p), async_op=True)
+
+        def wait_bcast(work):
+            if work is not None:
+                work.wait()
+            torch.cuda.synchronize(self.device) if not self.lookahead else torch.cuda.current_stream(self.device).synchronize()
+
+        def update(p, q):                      # columns of panel q -= (panel p)(panel p)^T rows
+            J, Wc = panels[p]
+            Jq, Wq = panels[q]
+            c0 = Jq - (J + Wc)
+            gp._check(lib.sigp_dist_update(gp._h, J, Wc, c0, c0 + Wq), "dist_update")
+
         info = 0
-        for p, (J, Wc) in enumerate(panels):
-            own = self.owner(p)
-            ne = int(lib.sigp_dist_panel_elems(gp._h, J, Wc))
-            view = self._buf[:ne + 1]
-            if self.rank == own:
-                pinfo = C.c_int64(0)
-                gp._check(lib.sigp_dist_panel_factor(gp._h, J, Wc, C.byref(pinfo)), "dist_panel_factor")
-                gp._check(lib.sigp_dist_panel_pack(gp._h, J, Wc, C.c_void_p(view.data_ptr())), "dist_panel_pack")
-                view[ne] = float(pinfo.value)
-            if self.world > 1:
-                self.dist.broadcast(view, src=own)       # the block-row panel broadcast (RCCL over xGMI)
-            torch.cuda.synchronize(self.device)
-            info = int(view[ne].item())
-            if info != 0:
-                break
-            if self.rank != own:
-                gp._check(lib.sigp_dist_panel_unpack(gp._h, J, Wc, C.c_void_p(view.data_ptr())), "dist_panel_unpack")
-            for q in range(p + 1, len(panels)):        # rank-K update of the panels this rank owns
-                if self.owner(q) == self.rank:
-                    Jq, Wq = panels[q]
-                    c0 = Jq - (J + Wc)
-                    gp._check(lib.sigp_dist_update(gp._h, J, Wc, c0, c0 + Wq), "dist_update")
+        try:
+            if self.rank == self.owner(0):
+                factor_and_pack(0)
+            work = start_bcast(0)
+            for p in range(P):
+                J, Wc = panels[p]
+                wait_bcast(work)
+                work = None
+                info = int(view(p)[nelem[p]].item())
+                if info != 0:
+                    break
+                if self.rank != self.owner(p):
+                    gp._check(lib.sigp_dist_panel_unpack(gp._h, J, Wc, C.c_void_p(view(p).data_ptr())), "dist_panel_unpack")
+                mine = [q for q in range(p + 1, P) if self.owner(q) == self.rank]
+                nxt = p + 1
+                if self.lookahead and nxt < P:
+                    if self.owner(nxt) == self.rank:
+                        update(p, nxt)                         # the next panel's own columns first ...
+                        gp._check(lib.sigp_dist_mark(gp._h), "dist_mark")
+                        mine.remove(nxt)
+                        for q in mine:                         # ... the rest of this rank's updates run on the update stream
+                            update(p, q)
+                        mine = []
+                        factor_and_pack(nxt)                   # ... while the panel stream factors and packs panel p+1
+                    else:
+                        gp._check(lib.sigp_dist_sync(gp._h, 1), "dist_sync")   # buffer (p+1)%2 free: panel p-1 unpacked
+                    work = start_bcast(nxt)
+                for q in mine:
+                    update(p, q)
+                if not self.lookahead and nxt < P:
+                    if self.owner(nxt) == self.rank:
+                        factor_and_pack(nxt)
+                    work = start_bcast(nxt)
+            if work is not None:                   # non-SPD exit with a broadcast in flight: complete the collective
+                wait_bcast(work)
+        finally:
+            gp._check(lib.sigp_dist_sync(gp._h, 0), "dist_sync")
+            gp.set_option("dist_async", 0)
         out = np.zeros(4)
         m = 0 if gp._ride is None else gp._ride.shape[0]
         mean, var = np.zeros(max(m, 1)), np.zeros(max(m, 1))

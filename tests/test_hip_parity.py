@@ -308,16 +308,35 @@ for kind, n, d, W in (("rbf", 1100, 8, 2), ("netdiffusion", 700, 12, 1), ("mater
     X, y, Xs = O.synthetic_problem(n, d, 4242 + n, m=3)
     ell, sn = (np.sqrt(d), 1e-2) if kind != "netdiffusion" else (0.05, 1e-2)
     ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
-    with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W) as dg:
-        dg.fit(X, y, ell, sn, Xs=Xs)
-        mu, var = dg.predict(Xs)
-        mu2, var2 = dg.predict(Xs[:2] + 0.1)
-        L = dg.gp.L_tilde_
-    ref2 = O.fit_predict(X, y, Xs[:2] + 0.1, ell, sn, kind=kind, M=ref["M"], ref_idiom=False)
-    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
-    assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank)
-    assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank)
-    assert rel(dg.nlml_, ref["nlml"]) <= 1e-9 and rel(L, ref["L_tilde"]) <= 1e-11, (kind, rank)
+    Ls = []
+    for la in (True, False):               # look-ahead (panel p+1 broadcast overlaps the updates with panel p) and strict order
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la) as dg:
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            mu2, var2 = dg.predict(Xs[:2] + 0.1)
+            L, nl = dg.gp.L_tilde_, dg.nlml_
+            dg.fit(X, y * 2.0, ell, sn, Xs=Xs)          # a second fit on the same handle (buffer reuse)
+            mu3, _ = dg.predict(Xs)
+        ref2 = O.fit_predict(X, y, Xs[:2] + 0.1, ell, sn, kind=kind, M=ref["M"], ref_idiom=False)
+        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+        assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank, la)
+        assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la)
+        assert rel(nl, ref["nlml"]) <= 1e-9 and rel(L, ref["L_tilde"]) <= 1e-11, (kind, rank, la)
+        assert rel(mu3, 2.0 * ref["fmean"]) <= 1e-8, (kind, rank, la)
+        Ls.append(L)
+    assert np.array_equal(Ls[0], Ls[1]), "look-ahead changed the factor"
+# non-SPD: every rank learns the failing pivot from the broadcast panel and raises like np.linalg.cholesky
+X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
+X[300:350] = X[100:150]
+for la in (True, False):
+    with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=2, lookahead=la) as dg:
+        try:
+            dg.fit(X, y, 2.0, 0.0, Xs=Xs)
+            raise SystemExit("expected LinAlgError")
+        except np.linalg.LinAlgError as e:
+            assert 300 < e.info <= 350, e.info
+        dg.fit(X, y, 2.0, 1e-2, Xs=Xs)                  # the handle stays usable
+        assert np.isfinite(dg.nlml_)
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
 '''
