@@ -114,6 +114,19 @@ def main():
         gp.run_batch(W, min(K, args.group), ell[W:W + min(K, args.group)], sn[W:W + min(K, args.group)], concurrency=1, group=args.group)
         prof_all = gp.profile_get(); gp.profile(False)
         prof_all_fits = min(K, args.group)
+    m64 = None
+    if rank == 0 and world == 1 and not args.no_profile:
+        # "m = 1 (also report m = 64)" -- the same steps with 64 test points riding along each fit (untimed extra)
+        rng = np.random.default_rng(7)
+        Xs64 = rng.standard_normal((years, 64, d))
+        gp.upload_batch(Xb, yb, Xs64, group=args.group, concurrency=args.concurrency)
+        k64 = min(K, args.group)
+        gp.run_batch(W, k64, ell[W:W + k64], sn[W:W + k64], concurrency=args.concurrency, group=args.group)
+        torch.cuda.synchronize(); ta = time.perf_counter()
+        r64 = gp.run_batch(W, k64, ell[W:W + k64], sn[W:W + k64], concurrency=args.concurrency, group=args.group)
+        torch.cuda.synchronize(); tb64 = time.perf_counter() - ta
+        assert np.all(r64["info"] == 0) and np.all(np.isfinite(r64["var"]))
+        m64 = {"value": k64 / tb64, "unit": "fits/s", "steps": k64, "note": "same workload with m=64 test points per fit (ride-along rows), measured after the timed region"}
     elapsed = t1 - t0
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
@@ -133,7 +146,11 @@ def main():
                    "years_resident": years, "lockstep_group": args.group, "groups_in_flight": args.concurrency, "parallelism": "years sharded over %d GPU(s), no collective" % world},
         "whole_fit_tflops": value * flops_fit / 1e12 / world,
         "whole_fit_frac_of_fp64_mfma_peak": value * flops_fit / 1e12 / world / PEAK_F64_MFMA_TFLOPS,
+        # K~ = k(X,X) + sn I with k <= 1: eigenvalues in [sn, n + sn] -> cond(K~) <= (n + sn)/sn over the grid used
+        "cond_upper_bound": {"min": float((n + sn[W:].max()) / sn[W:].max()), "max": float((n + sn[W:].min()) / sn[W:].min())},
     }
+    if m64 is not None:
+        out["m64"] = m64
     if rank == 0:
         dom = prof["syrk128"]
         if dom["launches"] and dom["ms"] > 0:
@@ -166,6 +183,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # reference-idiom CPU path (oracle, call-for-call north/June1st.py:264-277) on the host cores, one fit
         ncpu = os.cpu_count()
+        cpu_model = "unknown"
+        try:
+            with open("/proc/cpuinfo") as f:
+                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+        except OSError:
+            pass
+        import scipy
         try:
             from threadpoolctl import threadpool_info
             ncpu = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [ncpu])
@@ -177,7 +201,7 @@ def main():
         ref = O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=True)
         tc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
-                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d)" % (nb, d, np.__version__, ncpu, os.cpu_count()),
+                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / SciPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d, CPU: %s)" % (nb, d, np.__version__, scipy.__version__, ncpu, os.cpu_count(), cpu_model),
                                "seconds": tc}
         t0 = time.perf_counter()
         O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=False)

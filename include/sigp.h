@@ -96,8 +96,9 @@ int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X
                    const double* y, int64_t stridey, const double* Xs, int64_t strideXs, int64_t n,
                    int64_t d, int64_t m, const double* ell, const double* sn_tilde, int concurrency,
                    double* out, double* mean, double* var);
-/* Same, with every input already resident in HBM (device pointers, same layout/strides):
- * the timed region of bench.py starts here. */
+/* The same batch in two steps: sigp_batch_upload copies the data sets (host pointers, same layout/strides as
+ * sigp_fit_batch) into HBM once, where they stay resident; sigp_batch_run then runs fits [first, first+count) on the
+ * resident data (fit i uses data set i % batch) -- the timed region of bench.py is one sigp_batch_run call. */
 int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t strideX, const double* y,
                       int64_t stridey, const double* Xs, int64_t strideXs, int64_t n, int64_t d, int64_t m);
 /* allocate the lockstep slots for (group, concurrency) ahead of time, so no allocation falls inside a timed batch_run */
