@@ -93,6 +93,7 @@ struct sigp_handle {
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
   int opt_pan_priority = 1;  // panel streams at high priority
   int opt_panel_ll = 0;      // panels up to this width are factored left-looking (0 = binary recursion only)
+  int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
@@ -419,6 +420,40 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
 
   int rc = panel(0, std::min(W, T));
   if (rc) return rc;
+  if (h->opt_schedule == 1) {
+    // Left-looking outer schedule: panel q (columns J..J+Wq) is brought up to date in two launches,
+    //   A(q): C_q -= L[:, 0 : J-W] L[q rows, 0 : J-W]^T   (all panels but the last one: K = 128 (J-W), up to n - 2*128 W)
+    //   B(q): C_q -= P_{q-1} P_{q-1}^T                    (the panel factored last: K = 128 W)
+    // and then factored, F(q).  A(q+1) only needs panels 0..q-1, so it runs on the update stream while the panel
+    // stream does B(q), F(q).  Each C tile is read and written twice per panel instead of once per EARLIER panel,
+    // and almost all flops run at K >= 1024.  The k order of every tile's sum is the same as in the right-looking
+    // schedule (panels in order, k ascending), so the factor is bit-identical.
+    hipEvent_t evF[2] = {s.ev_pan, s.ev_done};
+    if (la) HIPCHK(h, hipEventRecord(evF[0], sp));                 // F(0)
+    int q = 1;
+    for (int J = W; J < T; J += W, ++q) {
+      const int Wq = std::min(W, T - J);
+      if (la) {
+        if (q >= 2) {
+          HIPCHK(h, hipStreamWaitEvent(su, evF[q & 1], 0));          // F(q-2) done (same parity as q)
+          if ((rc = update(su, SIGP_KC_SYRK128, 0, J - W, J, 0, Wq))) return rc;       // A(q)
+          HIPCHK(h, hipEventRecord(s.ev_la, su));
+          HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
+        }
+        if ((rc = update(sp, SIGP_KC_SYRK128, J - W, W, J, 0, Wq))) return rc;         // B(q), after F(q-1) in stream order
+        if ((rc = panel(J, Wq))) return rc;                                             // F(q)
+        HIPCHK(h, hipEventRecord(evF[q & 1], sp));
+      } else {
+        if ((rc = update(su, SIGP_KC_SYRK128, 0, J, J, 0, Wq))) return rc;             // A(q)+B(q) in one launch
+        if ((rc = panel(J, Wq))) return rc;
+      }
+    }
+    if (la) {
+      HIPCHK(h, hipEventRecord(s.ev_pan, sp));
+      HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
+    }
+    return SIGP_OK;
+  }
   for (int J = 0; J < T; J += W) {
     const int Wc = std::min(W, T - J);
     const int ncols = T - (J + Wc);            // trailing column blocks
@@ -772,6 +807,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     return SIGP_OK;
   }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }

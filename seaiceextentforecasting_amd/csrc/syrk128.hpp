@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = SET ? (T)0 : -Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr];
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = (SET || (g.dbg & 8)) ? (T)0 : -Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr];
 
   // DMA coordinates: per wave-instruction 8 rows x 128 B; lane -> (row = lane>>3, slot' = lane&7)
   const int drow_ = wave * 8 + (lane >> 3);                  // + 32*p
@@ -97,10 +97,12 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
     const T* Bb = Bs + buf * SY_T * KTe + brow0;
+    if (!(g.dbg & 2) || s == 0) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
+      for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
+      for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (g.dbg & 64) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     if (!(g.dbg & 4)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
     if (s + 2 < nst && !(g.dbg & 1)) SY_ISSUE((s + 2) * KTe, buf);
-    if (s + 1 < nst) {
+    if (s + 1 < nst && !(g.dbg & 2)) {
       const T* An = As + (buf ^ 1) * SY_T * KTe + arow0;
       const T* Bn = Bs + (buf ^ 1) * SY_T * KTe + brow0;
 #pragma unroll
@@ -133,12 +135,14 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   }
 #undef SY_ISSUE
 
+  if (!(g.dbg & 16) || acc[0][0][0] == (T)12345.678) {   // dbg 16: timing ablation without the C store
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+        for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+  }
   if (g.stamp && tid == 0) {
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);

@@ -28,7 +28,7 @@ class LinAlgError(np.linalg.LinAlgError):
 
 
 class GPR:
-    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None):
+    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None, schedule=None):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
         if dtype not in ("f64", "f32"):
@@ -55,6 +55,8 @@ class GPR:
             self.set_option("lookahead", int(bool(lookahead)))
         if reserve_cus is not None:
             self.set_option("reserve_cus", reserve_cus)
+        if schedule is not None:      # "right" | "left": outer schedule of the blocked Cholesky (same factor, bit for bit)
+            self.set_option("schedule", {"right": 0, "left": 1}[schedule])
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc, what):

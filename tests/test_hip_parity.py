@@ -240,7 +240,9 @@ def test_nlml_grid_matches_oracle(S):
 
 
 @pytest.mark.parametrize("opts", [dict(outer_blocks=1, lookahead=0), dict(outer_blocks=2, lookahead=1),
-                                  dict(outer_blocks=5, lookahead=1), dict(outer_blocks=16, lookahead=1)])
+                                  dict(outer_blocks=5, lookahead=1), dict(outer_blocks=16, lookahead=1),
+                                  dict(outer_blocks=2, lookahead=1, schedule="left"), dict(outer_blocks=2, lookahead=0, schedule="left"),
+                                  dict(outer_blocks=1, lookahead=1, schedule="left"), dict(outer_blocks=3, lookahead=1, schedule="left")])
 def test_blocking_options_do_not_change_results(S, opts):
     """Panel width / look-ahead only reorder launches: the factor is bitwise the same (fp64 sums in the same k order)."""
     X, y, Xs = O.synthetic_problem(1100, 8, 123, m=2)

@@ -21,6 +21,13 @@ if mode == "ablate":
             for dbg in (0, 64, 0, 64):
                 lib.sigp_debug_time_syrk(h, rt, K, 0, small, 5, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
                 print("%2d %4d %5d %3d | %6.3f  %6.1f   in-kernel clock %.2f GHz" % (rt, K, small, dbg, ms.value, tf.value, ghz.value))
+elif mode == "ablate2":
+    # dbg bits: 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no C load, 16 no C store  (timing only; results are garbage)
+    print("rt   K dbg |    ms   TFLOP/s  clock")
+    for rt, K in ((90, 1024), (90, 4096)):
+        for dbg in (0, 1, 4, 5, 2, 3, 7, 24, 25, 31, 0):
+            lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 4, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
+            print("%2d %4d %3d | %6.3f  %6.1f   %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
 else:
     rt, K, small = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     lib.sigp_debug_time_syrk(h, rt, K, 0, small, 3, C.byref(ms), C.byref(tf), 0, None)
