@@ -45,7 +45,7 @@ template <> struct Num<float> {
 
 constexpr int KT = Num<double>::KT;   // (fp64 names kept for the fp64-only call sites)
 
-enum { GEMM_SUB = 0, GEMM_SET = 1 };
+enum { GEMM_SUB = 0, GEMM_SET = 1, GEMM_SETNEG = 2 };   // C -= A B^T | C = A B^T | C = -A B^T
 
 template <typename T>
 struct GemmArgsT {
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   {                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                           \
       v16_t t = va[p];                                                                         \
-      if (MODE == GEMM_SUB) t = -t;                                                            \
+      if (MODE != GEMM_SET) t = -t;                                                            \
       *(v16_t*)(As + ((buf) * TM + arow + 32 * p) * LDPe + acp) = t;                           \
     }                                                                                          \
     if (BT) {                                                                                  \

@@ -195,6 +195,15 @@ __global__ void copy_block_kernel(const double* __restrict__ src, long lds, doub
 }
 
 // identity into a [n_pad][n_pad] buffer
+// panel_mode 1: diagonal blocks of the Mt workspace = the inverse diagonal blocks of the panel (grid: block j, member)
+template <typename T>
+__global__ void mt_diag_kernel(const T* __restrict__ dinv, long dinvStride, T* __restrict__ Mt, long ldm, long mtStride) {
+  const int j = blockIdx.x;
+  const T* src = dinv + (long)blockIdx.y * dinvStride + (long)j * 128 * 128;
+  T* dst = Mt + (long)blockIdx.y * mtStride + (long)j * 128 * ldm + (long)j * 128;
+  for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) dst[(long)(e >> 7) * ldm + (e & 127)] = src[e];
+}
+
 __global__ void set_identity_kernel(double* __restrict__ U, long ld, int n_pad) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)n_pad * n_pad) return;

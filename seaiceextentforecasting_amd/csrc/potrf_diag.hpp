@@ -48,6 +48,9 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v2_t v2_t;
+  // latency chain on the critical path of every panel, co-resident with MFMA-saturating update waves: ask the
+  // instruction arbiter for the highest wave priority (bit 32 of `skip` disables it, for A/B timing)
+  if (!(skip & 32)) __builtin_amdgcn_s_setprio(3);
   A += blockIdx.x * strideA;
   Linv += blockIdx.x * strideL;
   info += blockIdx.x;

@@ -11,6 +11,7 @@
 #include <limits>
 #include <chrono>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sigp.h"
@@ -43,6 +44,7 @@ struct Slot {
   int* info_host = nullptr;   // pinned
   KParams* kps = nullptr;     // device [capB] per-member hyper-parameters / data-set index
   KParams* kps_host = nullptr;// pinned
+  double* mt = nullptr; int cap_mt = 0;   // panel_mode 1: [cap_mt][MT_LD][MT_LD] pre-multiplied top blocks (see panel_strip_kernel)
   hipStream_t s_upd = nullptr, s_pan = nullptr;
   hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
 };
@@ -88,11 +90,15 @@ struct sigp_handle {
   double sigma_f = 0, nlml = 0;
   KParams kp{};
   // options
-  int opt_outer = 2;       // outer panel width in 128-blocks
+  int opt_outer = 8;       // outer panel width in 128-blocks (K = 1024 trailing updates; single fits: 8.7 vs 9.0 ms at n = 8192, 34.6 vs 42.1 ms at n = 16384 against 2)
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
   int opt_pan_priority = 1;  // panel streams at high priority
   int opt_panel_ll = 0;      // panels up to this width are factored left-looking (0 = binary recursion only)
+  int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
+                             // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
+  int opt_strip_min = 512;
+  int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
@@ -181,6 +187,8 @@ void slot_free_buffers(Slot& s) {
   if (s.info_host) (void)hipHostFree(s.info_host);
   if (s.kps) (void)hipFree(s.kps);
   if (s.kps_host) (void)hipHostFree(s.kps_host);
+  if (s.mt) (void)hipFree(s.mt);
+  s.mt = nullptr; s.cap_mt = 0;
   s.mat = s.dinv = s.res = s.res_host = nullptr; s.info = s.info_host = nullptr; s.kps = s.kps_host = nullptr;
   s.capB = 0; s.cap_npad = 0;
 }
@@ -218,6 +226,18 @@ void slot_free(Slot& s) {
   if (s.s_upd) (void)hipStreamDestroy(s.s_upd);
   if (s.s_pan) (void)hipStreamDestroy(s.s_pan);
   s = Slot();
+}
+
+constexpr int MT_W = 16;             // widest panel (in 128-blocks) the strip solve supports
+constexpr long MT_LD = MT_W * NB;    // row stride of a member's Mt workspace
+int slot_ensure_mt(sigp_handle* h, Slot& s, int nb) {
+  if (s.cap_mt >= nb) return SIGP_OK;
+  HIPCHK(h, hipDeviceSynchronize());
+  if (s.mt) HIPCHK(h, hipFree(s.mt));
+  s.mt = nullptr; s.cap_mt = 0;
+  HIPCHK(h, hipMalloc((void**)&s.mt, (size_t)nb * MT_LD * MT_LD * sizeof(double)));
+  s.cap_mt = nb;
+  return SIGP_OK;
 }
 
 // ---- profiling brackets -------------------------------------------------------------------------
@@ -345,6 +365,10 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const int R = T + 1;               // row blocks including the ride block
   const int W = std::max(1, h->opt_outer);
   constexpr int diag_lds = (36 * BSZ + DB) * (int)sizeof(Real);
+  if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
+    int rcm = slot_ensure_mt(h, s, nb);
+    if (rcm) return rcm;
+  }
   HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
   static bool diag_attr = false;
   if (!diag_attr) {
@@ -360,30 +384,32 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   }
 
   // lower-trapezoid update  C[cols ccol0.., rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
-  auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1) -> int {
+  auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1, int rlim) -> int {
     const long o = (long)ccol0 * NB;
     GemmArgsT<Real> g{};
     g.A = M + o * ld + (long)kcol0 * NB; g.lda = ld;
     g.B = g.A; g.ldb = ld;
     g.C = M + o * ld + o; g.ldc = ld;
     g.batch = nb; g.sA = g.sB = g.sC = matStride;
-    g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
+    g.K = kw * NB; g.r0 = 0; g.r1 = rlim - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
     (void)kclass;
     return gemm_sub_auto(h, st, g);
   };
   // factor block columns [J0, J0+Wp) (already up to date) by binary recursion: the left half, a rank-(half) update
   // of the right half's columns, then the right half.
-  std::function<int(int, int)> panel = [&](int J0, int Wp) -> int {
+  // rlim = one past the last row block the recursion touches: R for the whole panel, J0+Wp for its top block only
+  std::function<int(int, int, int)> panel_rec = [&](int J0, int Wp, int rlim) -> int {
     if (Wp == 1) {
       const int c = J0;
       {
         ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3, nb * 3.0 * NB * NB * 8);
         hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, M + (long)c * NB * ld + (long)c * NB, ld,
-                           dinvp + (long)c * NB * NB, s.info, c * NB, 0, matStride, dinvStride);
+                           dinvp + (long)c * NB * NB, s.info, c * NB, h->opt_diag_prio ? 0 : 32, matStride, dinvStride);
         HIPCHK(h, hipGetLastError());
       }
       const long o = (long)(c + 1) * NB;
-      const int rows_below = R - (c + 1);   // 128-row blocks below the diagonal block (ride block included)
+      const int rows_below = rlim - (c + 1);   // 128-row blocks below the diagonal block (ride block included when rlim = R)
+      if (rows_below <= 0) return SIGP_OK;
       GemmArgsT<Real> g{};
       g.A = M + o * ld + (long)c * NB; g.lda = ld;
       g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
@@ -403,19 +429,57 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       // (K = 128 (c-J0)), then factored: each panel column is read/written once and the average K doubles
       for (int i = 0; i < Wp; ++i) {
         int rc;
-        if (i > 0 && (rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, i, J0 + i, 0, 1))) return rc;
-        if ((rc = panel(J0 + i, 1))) return rc;
+        if (i > 0 && (rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, i, J0 + i, 0, 1, rlim))) return rc;
+        if ((rc = panel_rec(J0 + i, 1, rlim))) return rc;
       }
       return SIGP_OK;
     }
     const int hw = Wp / 2;
-    int rc = panel(J0, hw);
+    int rc = panel_rec(J0, hw, rlim);
     if (rc) return rc;
-    if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
-    return panel(J0 + hw, Wp - hw);
+    if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw, rlim))) return rc;
+    return panel_rec(J0 + hw, Wp - hw, rlim);
+  };
+  // factor block columns [J0, J0+Wp)
+  auto panel = [&](int J0, int Wp) -> int {
+    const int below = R - (J0 + Wp);             // row blocks under the panel's top block (the ride block is one of them)
+    const bool strips = std::is_same<Real, double>::value && Wp > 1 && Wp <= MT_W && below > 0 &&
+                        (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
+    if (!strips) return panel_rec(J0, Wp, R);
+    // panel_mode 1: recursion on the top Wp x Wp block only, then every 128-row strip below it is solved by one
+    // workgroup walking the panel's columns (panel_strip_kernel): the lower rows are read and written once
+    int rc = panel_rec(J0, Wp, J0 + Wp);
+    if (rc) return rc;
+    Real* mt = (Real*)s.mt;
+    const long mtStride = MT_LD * MT_LD;
+    {
+      ProfScope ps(h, sp, SIGP_KC_UPDATE_SMALL, nb * 2.0 * NB * NB * NB * (Wp * (Wp - 1) / 2), nb * 3.0 * NB * NB * 8 * (Wp * (Wp + 1) / 2));
+      hipLaunchKernelGGL(mt_diag_kernel<Real>, dim3(Wp, nb), dim3(256), 0, sp, dinvp + (long)J0 * NB * NB, dinvStride, mt, MT_LD, mtStride);
+      HIPCHK(h, hipGetLastError());
+      for (int j = 1; j < Wp; ++j) {             // Mt[j, 0:j] = -inv(L_jj) L[j, 0:j]
+        GemmArgsT<Real> g{};
+        g.A = dinvp + (long)(J0 + j) * NB * NB; g.lda = NB; g.sA = dinvStride;
+        g.B = M + (long)(J0 + j) * NB * ld + (long)J0 * NB; g.ldb = ld; g.sB = matStride;     // K x N row-major (BT)
+        g.C = mt + (long)j * NB * MT_LD; g.ldc = MT_LD; g.sC = mtStride;
+        g.batch = nb; g.K = NB; g.r0 = 0; g.r1 = 4; g.c0 = 0; g.c1 = j; g.lower = 0;
+        if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SETNEG, true>(h, sp, g))) return rc;
+      }
+    }
+    {
+      ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (double)below * 2.0 * NB * NB * NB * (Wp * (Wp + 1) / 2), nb * (double)below * 2.0 * Wp * NB * NB * 8);
+      static bool strip_attr = false;
+      if (!strip_attr) {
+        HIPCHK(h, hipFuncSetAttribute((const void*)panel_strip_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+        strip_attr = true;
+      }
+      StripArgsT<Real> a{M, ld, matStride, mt, MT_LD, mtStride, J0 + Wp, J0, Wp};
+      hipLaunchKernelGGL(panel_strip_kernel<Real>, dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
+      HIPCHK(h, hipGetLastError());
+    }
+    return SIGP_OK;
   };
   auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
-    return update(st, SIGP_KC_SYRK128, J, Wc, J + Wc, c0, c1);
+    return update(st, SIGP_KC_SYRK128, J, Wc, J + Wc, c0, c1, R);
   };
 
   int rc = panel(0, std::min(W, T));
@@ -436,15 +500,15 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       if (la) {
         if (q >= 2) {
           HIPCHK(h, hipStreamWaitEvent(su, evF[q & 1], 0));          // F(q-2) done (same parity as q)
-          if ((rc = update(su, SIGP_KC_SYRK128, 0, J - W, J, 0, Wq))) return rc;       // A(q)
+          if ((rc = update(su, SIGP_KC_SYRK128, 0, J - W, J, 0, Wq, R))) return rc;    // A(q)
           HIPCHK(h, hipEventRecord(s.ev_la, su));
           HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
         }
-        if ((rc = update(sp, SIGP_KC_SYRK128, J - W, W, J, 0, Wq))) return rc;         // B(q), after F(q-1) in stream order
+        if ((rc = update(sp, SIGP_KC_SYRK128, J - W, W, J, 0, Wq, R))) return rc;      // B(q), after F(q-1) in stream order
         if ((rc = panel(J, Wq))) return rc;                                             // F(q)
         HIPCHK(h, hipEventRecord(evF[q & 1], sp));
       } else {
-        if ((rc = update(su, SIGP_KC_SYRK128, 0, J, J, 0, Wq))) return rc;             // A(q)+B(q) in one launch
+        if ((rc = update(su, SIGP_KC_SYRK128, 0, J, J, 0, Wq, R))) return rc;          // A(q)+B(q) in one launch
         if ((rc = panel(J, Wq))) return rc;
       }
     }
@@ -807,6 +871,9 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     return SIGP_OK;
   }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
@@ -1272,6 +1339,7 @@ int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency) {
   for (int k = 0; k < concurrency; ++k) {
     int rc = slot_reserve(h, h->slots[k], h->b_npad, (int)group);
     if (rc) return rc;
+    if (h->opt_panel_mode != 0 && (rc = slot_ensure_mt(h, h->slots[k], (int)group))) return rc;
   }
   h->nslots = std::max(h->nslots, concurrency);
   return SIGP_OK;

@@ -27,44 +27,34 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // SET = true :  C  = A B^T   (panel solve L21 = A21 inv(L11)^T, in place: a tile reads only its own rows of A = C)
 // T = double: v_mfma_f64_16x16x4_f64, one 16-byte fragment read feeds 2 k-steps; T = float: v_mfma_f32_16x16x4_f32,
 // one read feeds 4 k-steps (same LDS / DMA bytes per MFMA-cycle, so the pipeline balance is the same).
+// One 128x128 tile:  C (-)= A[128 x K] B[128 x K]^T.  Ag / Bg point at the tile's first A / B row, Cw at THIS WAVE's
+// 64x64 quadrant of the C tile.  All 256 threads of the workgroup call it together (it contains barriers); As / Bs are
+// the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
 template <typename T, bool SET>
-__global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
+__device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
+                                             long ldc, int K, int dbg, T* As, T* Bs) {
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v16_t v16_t;
   constexpr int KTe = N_::KT, NE = N_::NE;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* As = (T*)smem_raw;                 // [2][128][KT]
-  T* Bs = As + 2 * SY_T * KTe;          // [2][128][KT]
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
-  int bi, bj;
-  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
-  const long bz = blockIdx.y;
-  const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
-  const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
-  T* Cg = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
-
-  unsigned long long st_c0 = 0, st_r0 = 0;
-  if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   acc_t acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = (SET || (g.dbg & 8)) ? (T)0 : -Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr];
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = (SET || (dbg & 8)) ? (T)0 : -Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr];
 
   // DMA coordinates: per wave-instruction 8 rows x 128 B; lane -> (row = lane>>3, slot' = lane&7)
   const int drow_ = wave * 8 + (lane >> 3);                  // + 32*p
   const int dks = ((lane & 7) ^ ((drow_ >> 1) & 7)) * NE;    // source k offset (elements) of this lane's 16 B
-  const T* Asrc = Ag + (long)drow_ * g.lda + dks;
-  const T* Bsrc = Bg + (long)drow_ * g.ldb + dks;
-  const long a32 = 32 * g.lda, b32 = 32 * g.ldb;
-
+  const T* Asrc = Ag + (long)drow_ * lda + dks;
+  const T* Bsrc = Bg + (long)drow_ * ldb + dks;
+  const long a32 = 32 * lda, b32 = 32 * ldb;
 #define SY_ISSUE(k0, buf)                                                                                     \
   {                                                                                                           \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                           \
@@ -84,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   //   read group-1 fragments of slice s | MFMA group 0 | barrier (slice s+1 landed, slice s fully read)
   //   | DMA slice s+2 into the buffer just freed, read group-0 fragments of slice s+1 | MFMA group 1
   // so every fragment read and every DMA has a whole MFMA group (2048 cycles) to land behind.
-  const int nst = g.K / KTe;
+  const int nst = K / KTe;
   v16_t a0[4], b0[4], a1[4], b1[4];
   SY_ISSUE(0, 0);
   __syncthreads();
@@ -97,26 +87,26 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
     const T* Bb = Bs + buf * SY_T * KTe + brow0;
-    if (!(g.dbg & 2) || s == 0) {
+    if (!(dbg & 2) || s == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (g.dbg & 64) __builtin_amdgcn_s_setprio(1);
+    if (dbg & 64) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
-    if (g.dbg & 64) __builtin_amdgcn_s_setprio(0);
+    if (dbg & 64) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.dbg & 4)) __syncthreads();
+    if (!(dbg & 4)) __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nst && !(g.dbg & 1)) SY_ISSUE((s + 2) * KTe, buf);
-    if (s + 1 < nst && !(g.dbg & 2)) {
+    if (s + 2 < nst && !(dbg & 1)) SY_ISSUE((s + 2) * KTe, buf);
+    if (s + 1 < nst && !(dbg & 2)) {
       const T* An = As + (buf ^ 1) * SY_T * KTe + arow0;
       const T* Bn = Bs + (buf ^ 1) * SY_T * KTe + brow0;
 #pragma unroll
@@ -135,17 +125,76 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   }
 #undef SY_ISSUE
 
-  if (!(g.dbg & 16) || acc[0][0][0] == (T)12345.678) {   // dbg 16: timing ablation without the C store
+  if (!(dbg & 16) || acc[0][0][0] == (T)12345.678) {   // dbg 16: timing ablation without the C store
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+        for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
   }
+}
+
+template <typename T, bool SET>
+__global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
+  constexpr int KTe = Num<T>::KT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = (T*)smem_raw;                 // [2][128][KT]
+  T* Bs = As + 2 * SY_T * KTe;          // [2][128][KT]
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  int bi, bj;
+  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
+  const long bz = blockIdx.y;
+  const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
+  const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
+  T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs);
   if (g.stamp && tid == 0) {
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+  }
+}
+
+// Panel solve by row strips (panel_mode 1).  The top Wp x Wp block of a panel is already factored and
+//   Mt = [ inv(L_00)                                   ]      (block row j: -inv(L_jj) L_jk for k < j, inv(L_jj) at k = j)
+//        [ -inv(L_11) L_10   inv(L_11)                 ]
+//        [ ...                                         ]
+// is given.  Block forward substitution of one 128-row strip below the top block,
+//   X_j = (A_j - sum_{k<j} X_k L_jk^T) inv(L_jj)^T  =  [X_0 .. X_{j-1} | A_j] [Mt_j0 .. Mt_jj]^T ,
+// is then ONE tile product per column block j with K = 128 (j+1), whose A operand is the strip itself as it stands
+// (columns < j already solved, column j still the input).  One workgroup walks j = 0 .. Wp-1 over its strip, so the
+// strip is read and written once from HBM and every flop of the panel's lower rows runs in the LDS-DMA MFMA loop.
+template <typename T>
+struct StripArgsT {
+  T* M; long ld; long sM;          // matrix, row stride, member stride
+  const T* Mt; long ldm; long sMt; // Mt workspace [Wp*128][ldm] per member
+  int rb0;                         // first row block of the strips (blockIdx.x = strip)
+  int J;                           // first column block of the panel
+  int Wp;                          // panel width in column blocks
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void panel_strip_kernel(StripArgsT<T> g) {
+  constexpr int KTe = Num<T>::KT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = (T*)smem_raw;
+  T* Bs = As + 2 * SY_T * KTe;
+  const int wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long bz = blockIdx.y;
+  T* strip = g.M + bz * g.sM + (long)(g.rb0 + blockIdx.x) * SY_T * g.ld + (long)g.J * SY_T;
+  const T* Mt = g.Mt + bz * g.sMt;
+  for (int j = 0; j < g.Wp; ++j) {
+    syrk128_tile<T, true>(strip, g.ld, Mt + (long)j * SY_T * g.ldm, g.ldm, strip + (long)(wm * 64) * g.ld + (long)j * SY_T + wn * 64, g.ld,
+                          SY_T * (j + 1), 0, As, Bs);
+    // X_j is the A operand of the next column.  Producer and consumer are the same workgroup (one CU, one L1/L2
+    // path), so workgroup scope is enough: __syncthreads() waits for this wave's stores (vmcnt) and for everyone's
+    // fragment reads of this tile before the next tile's DMA refills the LDS buffers.  (An agent-scope fence here
+    // writes back / invalidates the XCD's L2 on gfx950 and cost 10 % of the whole fit.)
+    __syncthreads();
   }
 }
 

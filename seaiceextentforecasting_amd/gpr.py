@@ -28,7 +28,8 @@ class LinAlgError(np.linalg.LinAlgError):
 
 
 class GPR:
-    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None, schedule=None):
+    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None, schedule=None,
+                 panel_mode=None):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
         if dtype not in ("f64", "f32"):
@@ -57,6 +58,8 @@ class GPR:
             self.set_option("reserve_cus", reserve_cus)
         if schedule is not None:      # "right" | "left": outer schedule of the blocked Cholesky (same factor, bit for bit)
             self.set_option("schedule", {"right": 0, "left": 1}[schedule])
+        if panel_mode is not None:    # "recursive" | "strips" | "auto": how the rows below a panel's top block are solved
+            self.set_option("panel_mode", {"recursive": 0, "strips": 1, "auto": 2}[panel_mode])
 
     # ---- plumbing ------------------------------------------------------------------------------
     def _check(self, rc, what):

@@ -253,6 +253,46 @@ def test_blocking_options_do_not_change_results(S, opts):
         assert g0.nlml_ == g1.nlml_
 
 
+@pytest.mark.parametrize("kind", ["rbf", "netdiffusion"])
+@pytest.mark.parametrize("n,W", [(257, 2), (1100, 2), (1100, 4), (2100, 8), (1300, 16), (900, 3)])
+def test_strip_panel_mode_matches_oracle(S, kind, n, W):
+    """panel_mode='strips' (top block by recursion, the rows below by panel_strip_kernel with pre-multiplied inverse
+    blocks) is a different association of the same block forward substitution: same tolerances as the default path,
+    and bit-identical with itself across look-ahead on/off."""
+    d = 8
+    X, y, Xs = O.synthetic_problem(n, d, 900 + n + W, m=3)
+    ell, sn = (np.sqrt(d), 1e-2) if kind == "rbf" else (0.05, 1e-2)
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    Ls = []
+    for la in (1, 0):
+        with S.GPR(kernel=kind, outer_blocks=W, lookahead=la, panel_mode="strips") as gp:
+            gp.fit(X, y, ell, sn, M=ref["M"], Xs=Xs)
+            mu, var = gp.predict(Xs)
+            L = gp.L_tilde_
+            assert rel(L, ref["L_tilde"]) <= 1e-11 and rel(gp.nlml_, ref["nlml"]) <= 1e-9
+            assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= TOL_PRED
+            assert rel(gp.alpha_, ref["alpha"]) <= 1e-8
+            Ls.append(L)
+    assert np.array_equal(Ls[0], Ls[1])
+
+
+def test_strip_panel_mode_batch_and_failure(S):
+    """Lockstep batch in strips mode == sequential default-mode fits to parity tolerance; a non-SPD member reports its pivot."""
+    n, d, B = 700, 6, 5
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 2, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 31 + b, m=2)
+    Xb[3, 300:350] = Xb[3, 100:150]
+    ell = np.full(B, 2.0); sn = np.array([1e-2, 1e-1, 1e-3, 0.0, 1e-2])
+    with S.GPR(kernel="rbf", outer_blocks=2, panel_mode="strips") as gp:
+        r = gp.fit_batch(Xb, yb, Xsb, ell, sn, concurrency=1, group=5)
+    assert r["info"][3] > 300 and np.all(np.delete(r["info"], 3) == 0)
+    for b in (0, 1, 2, 4):
+        ref = O.fit_predict(Xb[b], yb[b], Xsb[b], ell[b], sn[b], kind="rbf", ref_idiom=False)
+        assert rel(r["mean"][b], ref["fmean"]) <= TOL_PRED and rel(r["var"][b], ref["fvar"]) <= TOL_PRED
+        assert rel(r["nlml"][b], ref["nlml"]) <= 1e-9
+
+
 def test_full_size_properties_n4096(S):
     """BASELINE configs[1] (n=4096, d=8 RBF): oracle comparison + size-independent identities."""
     n, d = 4096, 8
@@ -295,6 +335,16 @@ def test_full_size_properties_n8192_batch(S):
         assert np.max(np.abs(Krows @ at - yb[0][rows])) <= 1e-8 * np.max(np.abs(yb[0]))
         mu2, var2 = gp.predict(Xb[0][:3])                                 # predicting at training points ~ interpolation
         assert np.all(var2 > 0) and np.all(np.abs(mu2 - yb[0][:3]) < 1.0)
+    # the bench configuration's panel path (strip solve below each panel's top block, lockstep group of 12 here) agrees
+    # with the recursive path of the fits above to the parity tolerance
+    ell12, sn12 = np.tile(ell, 4), np.tile(sn, 4)
+    with S.GPR(kernel="rbf", outer_blocks=8, panel_mode="strips") as gp:
+        r2 = gp.fit_batch(Xb, yb, Xsb, ell12, sn12, concurrency=1, group=12)
+    assert np.all(r2["info"] == 0)
+    for i in range(3):
+        assert rel(r2["mean"][i], r["mean"][i]) <= TOL_PRED and rel(r2["var"][i], r["var"][i]) <= TOL_PRED
+        assert rel(r2["nlml"][i], r["nlml"][i]) <= 1e-10 and rel(r2["sigma_f"][i], r["sigma_f"][i]) <= 1e-10
+    assert np.array_equal(r2["mean"][:3], r2["mean"][6:9])                # same (data set, hyper-parameters) -> same bits
 
 
 _DIST_WORKER = r'''
