@@ -11,6 +11,8 @@ extern "C" {
 #endif
 /* time potrf_diag_kernel on one 128x128 SPD block; `skip` bit mask switches phases off (tools/diag_bench.py) */
 int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps, double* ms_avg, double* L_out, double* Linv_out);
+/* time the covariance build for nb lockstep members of order n; flags: 2 no covariance function, 4 no store (tools/kbuild_bench.py) */
+int sigp_debug_time_kbuild(sigp_handle* h, int n, int d, int nb, int kernel_id, int flags, int reps, double* ms_avg);
 /* sustained v_mfma_f64_16x16x4_f64 rate; seed < 0: pseudo-random operands (tools/mfma_peak.py) */
 int sigp_debug_mfma_peak(sigp_handle* h, int blocks, int iters, double* tflops, double seed);
 /* time the lower-tile update on a synthetic panel: rt row tiles, depth K; small = 0 generic 128-tile kernel,

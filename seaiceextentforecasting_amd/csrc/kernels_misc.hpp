@@ -27,65 +27,86 @@ __device__ inline double cov_from_sq(const KParams& kp, double sq) {
 }
 
 // K5 (north/June1st.py:265 with an RBF / Matern-5/2 covariance in place of X Sigma X^T):
-// lower 64x64 tiles of K~ = k(X,X) + sn I, identity on the padding rows/cols (i or j >= n).
-// X is [n_pad][dp] row-major, zero padded.  Each wave writes two 512-B row segments per store (16 B per lane).
-constexpr int KB_T = 64;    // tile
-constexpr int KB_DC = 32;   // feature chunk staged in LDS
-// blockIdx.z = batch member; its hyper-parameters and data set come from kps[z].
+// K~ = k(X,X) + sn I in 64-row x 128-column tiles, identity on the padding rows/cols (i or j >= n).
+// X is [n_pad][dp] row-major, zero padded.  A thread owns 8 rows x 4 consecutive columns (per feature: 8 broadcast
+// LDS reads + two 16-byte reads for 32 elements), a wave writes two 1-KiB row segments per store.
+// Lower-triangle build (flags bit 0 clear): a 1-D grid over exactly the tiles that touch the lower triangle
+// (kbuild_tiles(n_pad) of them; tiles on the diagonal also fill the part of the upper triangle they cover, which
+// nothing reads).  flags bit 0 set ("full", derivative matrices): 2-D grid (n_pad/128, n_pad/64), every tile, zeros
+// instead of the identity on the padding.  blockIdx.z = batch member; hyper-parameters and data set from kps[z].
+constexpr int KB_TM = 64;    // tile rows
+constexpr int KB_TN = 128;   // tile columns
+constexpr int KB_DC = 32;    // feature chunk staged in LDS
+inline long kbuild_tiles(long n_pad) { const long T = n_pad / KB_TN; return T * (T + 1); }
+template <typename TO>
+struct alignas(4 * sizeof(TO)) KbOut4 { TO v[4]; };
+
 template <typename TO>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
-                                                     const KParams* __restrict__ kps, int full) {
-  typedef typename Num<TO>::v2_t v2_t;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj > bi && !full) return;   // full = 1: every tile, zero (not identity) on the padding (derivative matrices)
+                                                     const KParams* __restrict__ kps, int flags) {
+  const int full = flags & 1;      // flag bits 2 / 4: timing ablations (no covariance function / no store)
+  int bi, bj;                      // 64-row tile, 128-column tile
+  if (full) {
+    bi = blockIdx.y; bj = blockIdx.x;
+  } else {                         // row-tile pair k = (2k, 2k+1) has column tiles 0..k
+    const int u = blockIdx.x >> 1;
+    int k = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
+    while ((k + 1) * (k + 2) / 2 <= u) ++k;
+    while (k * (k + 1) / 2 > u) --k;
+    bj = u - k * (k + 1) / 2;
+    bi = 2 * k + (blockIdx.x & 1);
+  }
   const KParams kp = kps[blockIdx.z];
   X += kp.ds * strideX;
   Mat += blockIdx.z * strideM;
-  __shared__ double Xi[KB_T][KB_DC + 1];
-  __shared__ __attribute__((aligned(16))) double XjT[KB_DC][KB_T + 2];
+  __shared__ double Xi[KB_TM][KB_DC + 1];
+  __shared__ __attribute__((aligned(16))) double XjT[KB_DC][KB_TN + 2];
   const int tid = threadIdx.x;
-  const int c2 = (tid & 31) * 2, rg = tid >> 5;
-  double acc[8][2];
+  const int c4 = (tid & 31) * 4, rg = tid >> 5;
+  double acc[8][4];
 #pragma unroll
-  for (int s = 0; s < 8; ++s) acc[s][0] = acc[s][1] = 0.0;
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[s][c] = 0.0;
   for (int p0 = 0; p0 < d; p0 += KB_DC) {
     const int pc = min(KB_DC, d - p0);
     __syncthreads();
-    for (int idx = tid; idx < KB_T * KB_DC; idx += 256) {
-      const int r = idx / KB_DC, p = idx % KB_DC;
-      double vi = 0.0, vj = 0.0;
-      if (p < pc) {
-        vi = X[(long)(bi * KB_T + r) * dp + p0 + p];
-        vj = X[(long)(bj * KB_T + r) * dp + p0 + p];
-      }
-      Xi[r][p] = vi;
-      XjT[p][r] = vj;
+    // staging: lanes run along the rows, so the transposed image XjT[p][r] is written conflict-free and only the
+    // pc live features are touched (the strided 8-byte global reads hit the same lines again for the next p)
+    for (int idx = tid; idx < KB_TN * pc; idx += 256) {
+      const int r = idx & (KB_TN - 1), p = idx >> 7;
+      XjT[p][r] = X[(long)(bj * KB_TN + r) * dp + p0 + p];
+    }
+    for (int idx = tid; idx < KB_TM * pc; idx += 256) {
+      const int r = idx & (KB_TM - 1), p = idx >> 6;
+      Xi[r][p] = X[(long)(bi * KB_TM + r) * dp + p0 + p];
     }
     __syncthreads();
     for (int p = 0; p < pc; ++p) {
-      const d2 b = *(const d2*)(&XjT[p][c2]);
+      const d2 b01 = *(const d2*)(&XjT[p][c4]);
+      const d2 b23 = *(const d2*)(&XjT[p][c4 + 2]);
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const double a = Xi[rg + 8 * s][p];
-        const double d0 = a - b.x, d1 = a - b.y;
+        const double d0 = a - b01.x, d1 = a - b01.y, d2_ = a - b23.x, d3 = a - b23.y;
         acc[s][0] += d0 * d0;
         acc[s][1] += d1 * d1;
+        acc[s][2] += d2_ * d2_;
+        acc[s][3] += d3 * d3;
       }
     }
   }
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
-    const int gi = bi * KB_T + rg + 8 * s, gj = bj * KB_T + c2;
-    v2_t v;
-    if (gi >= n) {
-      v.x = (TO)((gi == gj && !full) ? 1.0 : 0.0);
-      v.y = (TO)((gi == gj + 1 && !full) ? 1.0 : 0.0);
-    } else {
-      v.x = (TO)((gj < n) ? cov_from_sq(kp, acc[s][0]) + (gi == gj ? kp.sn : 0.0) : 0.0);
-      v.y = (TO)((gj + 1 < n) ? cov_from_sq(kp, acc[s][1]) + (gi == gj + 1 ? kp.sn : 0.0) : 0.0);
+    const int gi = bi * KB_TM + rg + 8 * s, gj = bj * KB_TN + c4;
+    KbOut4<TO> o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (gi >= n) o.v[c] = (TO)((gi == gj + c && !full) ? 1.0 : 0.0);
+      else o.v[c] = (TO)((gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq(kp, acc[s][c])) + (gi == gj + c ? kp.sn : 0.0) : 0.0);
     }
-    *(v2_t*)(Mat + (long)gi * ld + gj) = v;
+    if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + gj) = o;
   }
 }
 

@@ -345,7 +345,7 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
               long strideXs, long n, long d, long dp, long n_pad, long m) {
   const long ld = n_pad;
   ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
-  dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), (unsigned)nb);
+  dim3 grid((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb);
   hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
@@ -727,7 +727,7 @@ int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* 
   if ((rc = upload_kparams(h, s, 1))) return rc;
   {
     ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * n / 2 * (3.0 * d + 20), 8.0 * n * d + 2.0 * n * (n + 1));
-    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), 1);
+    dim3 grid((unsigned)kbuild_tiles(n_pad), 1, 1);
     hipLaunchKernelGGL(kbuild_kernel<float>, grid, dim3(256), 0, st, X, 0L, (int)dp, (int)d, (int)n, h->fmat, 0L, ld, s.kps, 0);
     HIPCHK(h, hipGetLastError());
     dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, 1);
@@ -1503,7 +1503,7 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   } else {
     s.kps_host[0] = make_kparams(kernel_id == SIGP_KERNEL_RBF ? KID_RBF_DLOGL : KID_MATERN52_DLOGL, ell, 0.0, 0);
     if ((rc = upload_kparams(h, s, 1))) return rc;
-    dim3 grid((unsigned)(n_pad / KB_T), (unsigned)(n_pad / KB_T), 1);
+    dim3 grid((unsigned)(n_pad / KB_TN), (unsigned)(n_pad / KB_TM), 1);
     hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
     HIPCHK(h, hipGetLastError());
   }
@@ -1742,6 +1742,37 @@ int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps,
   if (Linv_out) HIPCHK(h, hipMemcpy(Linv_out, li, NB * NB * 8, hipMemcpyDeviceToHost));
   (void)hipFree(a0); (void)hipFree(a1); (void)hipFree(li); (void)hipFree(info);
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  return SIGP_OK;
+}
+
+// time kbuild_kernel for nb lockstep members of order n (flags: 2 no covariance function, 4 no store)
+int sigp_debug_time_kbuild(sigp_handle* h, int n, int d, int nb, int kernel_id, int flags, int reps, double* ms_avg) {
+  if (!h || n < 128 || n % 128 || d < 1 || d > 64 || nb < 1 || reps < 1) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  const long dp = round_up(d, 8), ld = n;
+  double *X, *Mat; KParams* kps;
+  HIPCHK(h, hipMalloc((void**)&X, (size_t)n * dp * 8)); HIPCHK(h, hipMalloc((void**)&Mat, (size_t)nb * n * n * 8));
+  HIPCHK(h, hipMalloc((void**)&kps, (size_t)nb * sizeof(KParams)));
+  std::vector<double> hx((size_t)n * dp, 0.0);
+  for (long i = 0; i < n; ++i) for (int p = 0; p < d; ++p) hx[i * dp + p] = 1e-3 * (double)(((i * dp + p) * 2654435761u) % 4000) - 2.0;
+  HIPCHK(h, hipMemcpy(X, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
+  std::vector<KParams> hk((size_t)nb, make_kparams(kernel_id, std::sqrt((double)d), 1e-2, 0));
+  HIPCHK(h, hipMemcpy(kps, hk.data(), hk.size() * sizeof(KParams), hipMemcpyHostToDevice));
+  hipStream_t st = h->slots[0].s_upd;
+  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+  double tot = 0;
+  for (int r = 0; r < reps + 2; ++r) {
+    HIPCHK(h, hipEventRecord(e0, st));
+    hipLaunchKernelGGL(kbuild_kernel<double>, dim3((unsigned)kbuild_tiles(n), 1, (unsigned)nb), dim3(256), 0, st, X, 0L, (int)dp, d, n, Mat,
+                       (long)n * n, ld, kps, flags & ~1);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipEventRecord(e1, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (r >= 2) tot += ms;
+  }
+  if (ms_avg) *ms_avg = tot / reps;
+  (void)hipFree(X); (void)hipFree(Mat); (void)hipFree(kps); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return SIGP_OK;
 }
 

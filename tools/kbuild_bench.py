@@ -1,0 +1,16 @@
+"""Ablation timing of the covariance build (debug entry sigp_debug_time_kbuild)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from seaiceextentforecasting_amd import _lib as L
+lib = L.load()
+lib.sigp_debug_time_kbuild.restype = C.c_int
+lib.sigp_debug_time_kbuild.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, L._dp]
+h = C.c_void_p(); assert lib.sigp_create(C.byref(h), 0, 0) == 0
+ms = C.c_double()
+for n, d, nb in ((8192, 8, 8), (8192, 8, 40), (8192, 32, 8)):
+    for kid, kname in ((1, "rbf"), (2, "matern52")):
+        for flags in (0, 2, 4, 6):
+            rc = lib.sigp_debug_time_kbuild(h, n, d, nb, kid, flags, 5, C.byref(ms))
+            assert rc == 0, rc
+            byt = nb * (4.0 * n * (n + 1) + 8.0 * n * d)
+            print("n=%d d=%2d nb=%2d %-8s flags=%d : %7.3f ms  %6.3f ms/member  %5.2f TB/s (lower-triangle bytes)" % (n, d, nb, kname, flags, ms.value, ms.value / nb, byt / ms.value / 1e9), flush=True)
