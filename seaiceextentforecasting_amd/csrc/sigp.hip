@@ -1813,7 +1813,7 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
   g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp; g.C = Cm; g.ldc = ldc; g.K = K; g.r0 = 0; g.r1 = rt; g.c0 = 0; g.c1 = rt; g.lower = 1; g.patch = patch; g.dbg = dbg;
   unsigned long long* stamp = nullptr;
   const int ngrid = gemm_grid_size(0, rt, 0, rt, 1, patch);
-  if (clock_ghz && small == 2) { HIPCHK(h, hipMalloc((void**)&stamp, (size_t)ngrid * 16)); HIPCHK(h, hipMemset(stamp, 0, (size_t)ngrid * 16)); g.stamp = stamp; }
+  if (clock_ghz && small == 2) { HIPCHK(h, hipMalloc((void**)&stamp, (size_t)ngrid * 40)); HIPCHK(h, hipMemset(stamp, 0, (size_t)ngrid * 40)); g.stamp = stamp; }
   if (small == 1) { g.r1 *= 2; g.c1 *= 2; }
   double tot = 0;
   for (int r = 0; r < reps + 2; ++r) {
@@ -1826,8 +1826,13 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
     if (r >= 2) tot += ms;
   }
   if (stamp) {
-    std::vector<unsigned long long> hs((size_t)ngrid * 2);
+    std::vector<unsigned long long> hs((size_t)ngrid * 5);
     HIPCHK(h, hipMemcpy(hs.data(), stamp, hs.size() * 8, hipMemcpyDeviceToHost));
+    if (dbg & 256) {
+      double p0 = 0, p1 = 0, p2 = 0;
+      for (int i = 0; i < ngrid; ++i) { p0 += (double)hs[2 * (size_t)ngrid + 3 * i]; p1 += (double)hs[2 * (size_t)ngrid + 3 * i + 1]; p2 += (double)hs[2 * (size_t)ngrid + 3 * i + 2]; }
+      fprintf(stderr, "[syrk phases] cycles per tile (wave 0): prologue %.0f  K loop %.0f  epilogue %.0f\n", p0 / ngrid, p1 / ngrid, p2 / ngrid);
+    }
     double sc = 0, sr = 0;
     for (int i = 0; i < ngrid; ++i) { sc += (double)hs[2 * i]; sr += (double)(hs[2 * i + 1] >> 8); }
     if (dbg & 32) { fprintf(stderr, "[xcc by block]"); for (int i = 0; i < std::min(ngrid, 96); ++i) fprintf(stderr, " %d", (int)(hs[2 * i + 1] & 0xf)); fprintf(stderr, "\n"); }

@@ -32,7 +32,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
 template <typename T, bool SET>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
-                                             long ldc, int K, int dbg, T* As, T* Bs) {
+                                             long ldc, int K, int dbg, T* As, T* Bs, unsigned long long* phase = nullptr) {
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v16_t v16_t;
@@ -78,6 +78,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   v16_t a0[4], b0[4], a1[4], b1[4];
   SY_ISSUE(0, 0);
   __syncthreads();
+  if (phase) phase[0] = __builtin_amdgcn_s_memtime();   // C tile and first K-slice have landed
   if (nst > 1) SY_ISSUE(KTe, 1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
@@ -124,6 +125,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef SY_ISSUE
+  if (phase) phase[1] = __builtin_amdgcn_s_memtime();   // K loop issued
 
   if (!(dbg & 16) || acc[0][0][0] == (T)12345.678) {   // dbg 16: timing ablation without the C store
 #pragma unroll
@@ -151,7 +153,15 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs);
+  unsigned long long ph[2] = {0, 0};
+  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, g.stamp ? ph : nullptr);
+  if (g.stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid == 0) {
+      unsigned long long* o = g.stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
+      o[0] = ph[0] - st_c0; o[1] = ph[1] - ph[0]; o[2] = __builtin_amdgcn_s_memtime() - ph[1];
+    }
+  }
   if (g.stamp && tid == 0) {
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
     g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);

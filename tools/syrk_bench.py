@@ -28,6 +28,12 @@ elif mode == "ablate2":
         for dbg in (0, 1, 4, 5, 2, 3, 7, 24, 25, 31, 0):
             lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 4, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
             print("%2d %4d %3d | %6.3f  %6.1f   %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
+elif mode == "phases":
+    # dbg 256: in-kernel cycle counts of the three phases of a tile (printed on stderr by the debug entry)
+    for rt, K in ((127, 1024), (127, 512), (127, 128), (90, 4096)):
+        for dbg in (256, 256 + 1, 256 + 8 + 16):
+            lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 3, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
+            print("%3d %4d dbg %3d | %6.3f ms  %6.1f TFLOP/s  %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
 else:
     rt, K, small = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
     lib.sigp_debug_time_syrk(h, rt, K, 0, small, 3, C.byref(ms), C.byref(tf), 0, None)
