@@ -267,6 +267,13 @@ void prof_drain(sigp_handle* h) {
   h->pev.clear();
 }
 
+// hipFuncSetAttribute is per device: remember per (kernel instantiation, device) whether the dynamic-LDS limit was raised
+constexpr int MAX_DEVICES = 64;
+struct AttrOnce {
+  bool done[MAX_DEVICES] = {false};
+  bool need(int dev) { if (dev < 0 || dev >= MAX_DEVICES) return true; if (done[dev]) return false; done[dev] = true; return true; }
+};
+
 // ---- GEMM launch ----------------------------------------------------------------------------------
 template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT>
 int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
@@ -274,11 +281,8 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   if (nt <= 0) return SIGP_OK;
   auto kern = gemm_mfma_kernel<T, TM, TN, WM, WN, MODE, BT>;
   constexpr int lds = gemm_lds_bytes<T, TM, TN, BT>();
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done = true;
-  }
+  static AttrOnce attr;
+  if (attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(kern, dim3(nt, std::max(1, g.batch)), dim3(256), lds, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -291,11 +295,8 @@ template <typename T, bool SET>
 int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
-  static bool attr_done = false;
-  if (!attr_done) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<T, SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
-    attr_done = true;
-  }
+  static AttrOnce attr;
+  if (attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<T, SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
   hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -370,11 +371,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     if (rcm) return rcm;
   }
   HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
-  static bool diag_attr = false;
-  if (!diag_attr) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds));
-    diag_attr = true;
-  }
+  static AttrOnce diag_attr;
+  if (diag_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds));
   const bool la = h->opt_lookahead != 0;
   hipStream_t sp = la ? s.s_pan : s.s_upd;   // panel stream
   hipStream_t su = s.s_upd;
@@ -467,11 +465,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     }
     {
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (double)below * 2.0 * NB * NB * NB * (Wp * (Wp + 1) / 2), nb * (double)below * 2.0 * Wp * NB * NB * 8);
-      static bool strip_attr = false;
-      if (!strip_attr) {
-        HIPCHK(h, hipFuncSetAttribute((const void*)panel_strip_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
-        strip_attr = true;
-      }
+      static AttrOnce strip_attr;
+      if (strip_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)panel_strip_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
       StripArgsT<Real> a{M, ld, matStride, mt, MT_LD, mtStride, J0 + Wp, J0, Wp};
       hipLaunchKernelGGL(panel_strip_kernel<Real>, dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
       HIPCHK(h, hipGetLastError());
@@ -1539,11 +1534,8 @@ int sigp_dist_begin(sigp_handle* h) {
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "dist_begin: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  static bool diag_attr = false;
-  if (!diag_attr) {
-    HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-    diag_attr = true;
-  }
+  static AttrOnce diag_attr;
+  if (diag_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
   return sync_slot(h, s);
 }
