@@ -1708,10 +1708,12 @@ __global__ void whereami_kernel(unsigned* out) {
 
 // ---- debug / micro-benchmark entry points (not part of the product ABI; see tools/) -------------------
 int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps, double* ms_avg, double* L_out, double* Linv_out) {
-  if (!h || !A128 || reps < 1) return SIGP_BAD_ARG;
+  if (!h || !A128 || reps < 1 || reps > 4096) return SIGP_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
+  // `reps` copies of the block are factored by `reps` back-to-back launches between two events (a lone 60 us launch on
+  // an idle GPU is timed at whatever clock the chip idles at); 20 untimed launches first
   double *a0, *a1, *li; int* info;
-  HIPCHK(h, hipMalloc((void**)&a0, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&a1, NB * NB * 8));
+  HIPCHK(h, hipMalloc((void**)&a0, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&a1, (size_t)reps * NB * NB * 8));
   HIPCHK(h, hipMalloc((void**)&li, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&info, 4));
   HIPCHK(h, hipMemset(li, 0, NB * NB * 8));
   HIPCHK(h, hipMemcpy(a0, A128, NB * NB * 8, hipMemcpyHostToDevice));
@@ -1719,17 +1721,19 @@ int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps,
   HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
   hipStream_t st = h->slots[0].s_upd;
   hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  double tot = 0;
-  for (int r = 0; r < reps + 2; ++r) {
-    HIPCHK(h, hipMemcpyAsync(a1, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
+  float ms = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int r = 0; r < reps; ++r) HIPCHK(h, hipMemcpyAsync(a1 + (size_t)r * NB * NB, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
+    const int n = pass == 0 ? std::min(reps, 20) : reps;
     HIPCHK(h, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1, (long)NB, li, info, 0, skip, 0L, 0L);
+    for (int r = 0; r < n; ++r)
+      hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1 + (size_t)r * NB * NB, (long)NB, li, info, 0, skip, 0L, 0L);
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
-    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    if (r >= 2) tot += ms;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
   }
-  if (ms_avg) *ms_avg = tot / reps;
+  if (ms_avg) *ms_avg = ms / reps;
   if (L_out) HIPCHK(h, hipMemcpy(L_out, a1, NB * NB * 8, hipMemcpyDeviceToHost));
   if (Linv_out) HIPCHK(h, hipMemcpy(Linv_out, li, NB * NB * 8, hipMemcpyDeviceToHost));
   (void)hipFree(a0); (void)hipFree(a1); (void)hipFree(li); (void)hipFree(info);
