@@ -123,7 +123,9 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
  * torch.distributed (RCCL broadcast over xGMI on the GPU box).  Every rank holds the whole matrix buffer but
  * only updates the panels it owns; a factored panel is packed into a contiguous device buffer, broadcast,
  * and unpacked by the other ranks.  J, W, c0, c1 are in units of 128-column blocks.
- * Replaces the same np.linalg.cholesky call (north/June1st.py:265) as sigp_potrf. */
+ * Replaces the same np.linalg.cholesky call (north/June1st.py:265) as sigp_potrf.
+ * Works for both engines: on an fp32 handle (BASELINE configs[4]) sigp_kernel_build builds the fp32 matrix, the panels
+ * travel as fp32 (dev_buf holds floats) and sigp_dist_finish runs the fp64 iterative refinement on every rank. */
 int sigp_dist_begin(sigp_handle* h);                                   /* after sigp_kernel_build*: reset info  */
 int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W);  /* doubles in the packed panel J..J+W     */
 int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info);  /* owner: factor panel       */

@@ -547,42 +547,44 @@ int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
   return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad);
 }
 
-// stand-alone pieces of potrf_slot for the multi-GPU driver (one member, slot stream, no look-ahead)
-int dist_update(sigp_handle* h, Slot& s, hipStream_t st, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
+// stand-alone pieces of potrf_core for the multi-GPU driver (one member; Mm / dinvp = the fp64 slot matrix or the fp32 engine's)
+template <typename Real>
+int dist_update(sigp_handle* h, Real* Mm, hipStream_t st, long n_pad, int kcol0, int kw, int ccol0, int c0, int c1) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB), R = T + 1;
   const long o = (long)ccol0 * NB;
-  GemmArgs g{};
-  g.A = s.mat + o * ld + (long)kcol0 * NB; g.lda = ld;
+  GemmArgsT<Real> g{};
+  g.A = Mm + o * ld + (long)kcol0 * NB; g.lda = ld;
   g.B = g.A; g.ldb = ld;
-  g.C = s.mat + o * ld + o; g.ldc = ld;
+  g.C = Mm + o * ld + o; g.ldc = ld;
   g.batch = 1; g.sA = g.sB = g.sC = 0;
   g.K = kw * NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = 0;
   return gemm_sub_auto(h, st, g);
 }
 
-int dist_panel(sigp_handle* h, Slot& s, hipStream_t sp, long n_pad, int J0, int Wp) {
+template <typename Real>
+int dist_panel(sigp_handle* h, Slot& s, Real* Mm, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB), R = T + 1;
   if (Wp == 1) {
     const int c = J0;
-    hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, s.mat + (long)c * NB * ld + (long)c * NB, ld,
-                       s.dinv + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
+    hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, sp, Mm + (long)c * NB * ld + (long)c * NB, ld,
+                       dinvp + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
     HIPCHK(h, hipGetLastError());
     const long o = (long)(c + 1) * NB;
     const int rows_below = R - (c + 1);
-    GemmArgs g{};
-    g.A = s.mat + o * ld + (long)c * NB; g.lda = ld;
-    g.B = s.dinv + (long)c * NB * NB; g.ldb = NB;
-    g.C = s.mat + o * ld + (long)c * NB; g.ldc = ld;
+    GemmArgsT<Real> g{};
+    g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
+    g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
+    g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
     g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
-    return launch_gemm_cfg<32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+    return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   }
   const int hw = Wp / 2;
-  int rc = dist_panel(h, s, sp, n_pad, J0, hw);
+  int rc = dist_panel<Real>(h, s, Mm, dinvp, sp, n_pad, J0, hw);
   if (rc) return rc;
-  if ((rc = dist_update(h, s, sp, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
-  return dist_panel(h, s, sp, n_pad, J0 + hw, Wp - hw);
+  if ((rc = dist_update<Real>(h, Mm, sp, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
+  return dist_panel<Real>(h, s, Mm, dinvp, sp, n_pad, J0 + hw, Wp - hw);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
@@ -706,14 +708,16 @@ int f32_reserve(sigp_handle* h, long n_pad) {
   } while (0)
 
 // one fp32 fit on slot 0's streams from device-resident X [n_pad][dp], y [n_pad], Xs [128][dp] (m <= 3 ride points)
-int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
-            long dp, long n_pad, long m, double* out, double* mean, double* var) {
+// fp32 engine in three steps so that the multi-GPU driver can put its own panel loop in the middle:
+//   f32_build  fp32 kernel matrix + ride rows into fmat;   factor (potrf_core<float> or the sigp_dist_* panel loop);
+//   f32_finish reductions, x0, fp64 iterative refinement, results
+int f32_build(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
+              long dp, long n_pad, long m) {
   if (m > 3) return fail(h, SIGP_BAD_ARG, "fp32 engine: at most 3 ride-along test points (refinement solves 1+m systems)");
   if (d > 64) return fail(h, SIGP_BAD_ARG, "fp32 engine: d <= 64 required");
   Slot& s = h->slots[0];
   hipStream_t st = s.s_upd;
   const long ld = n_pad;
-  const int nrhs = (int)(1 + m);
   int rc;
   if ((rc = f32_reserve(h, n_pad))) return rc;
   if ((rc = slot_reserve(h, s, NB, 1))) return rc;     // res / info / kps buffers only
@@ -730,7 +734,17 @@ int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* 
                        h->fmat + n_pad * ld, 0L, ld, s.kps, 1);
     HIPCHK(h, hipGetLastError());
   }
-  if ((rc = potrf_core<float>(h, s, h->fmat, 0, h->fdinv, 0, 1, n_pad))) return rc;
+  return SIGP_OK;
+}
+
+int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
+               long dp, long n_pad, long m, double* out, double* mean, double* var) {
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long ld = n_pad;
+  const int nrhs = (int)(1 + m);
+  const KParams kp = make_kparams(kernel_id, ell, sn, 0);
+  int rc;
   {
     const float* Z = h->fmat + n_pad * ld;
     hipLaunchKernelGGL(epilogue_kernel<float>, dim3((unsigned)(m + 2), 1), dim3(256), 0, st, Z, ld, Z, (const float*)h->fmat, ld, (int)n,
@@ -798,6 +812,14 @@ int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* 
     if (var) var[j] = sf * (1.0 + sn - dots1[1 + j]);                       // k** + sn~ - k*^T K~^-1 k*
   }
   return SIGP_OK;
+}
+
+int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
+            long dp, long n_pad, long m, double* out, double* mean, double* var) {
+  int rc = f32_build(h, kernel_id, ell, sn, X, y, Xs, n, d, dp, n_pad, m);
+  if (rc) return rc;
+  if ((rc = potrf_core<float>(h, h->slots[0], h->fmat, 0, h->fdinv, 0, 1, n_pad))) return rc;
+  return f32_finish(h, kernel_id, ell, sn, X, y, Xs, n, d, dp, n_pad, m, out, mean, var);
 }
 
 int sync_slot(sigp_handle* h, Slot& s) {
@@ -947,8 +969,6 @@ int sigp_set_test(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs) {
 }
 
 int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde) {
-  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "kernel_build: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
-
   if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "kernel_build: call set_train first");
   if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "kernel_build: kernel_id must be RBF or MATERN52 (use kernel_build_from_sigma for the reference kernel)");
   if (!(ell > 0) || !(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "kernel_build: ell > 0 and sn_tilde >= 0 required");
@@ -956,6 +976,13 @@ int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde
   h->kp = make_kparams(kernel_id, ell, sn_tilde, 0);
   h->kernel_id = kernel_id; h->ell = ell; h->sn_tilde = sn_tilde;
   h->kss_unit.assign((size_t)h->m, 1.0);
+  if (h->dtype == SIGP_F32) {   // fp32 engine: the matrix goes to its own buffers; only the sharded panel loop (sigp_dist_*) continues from here
+    int rc32 = f32_build(h, kernel_id, ell, sn_tilde, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m);
+    if (rc32) return rc32;
+    if ((rc32 = sync_slot(h, h->slots[0]))) return rc32;
+    h->built = true; h->factored = h->fitted = false;
+    return SIGP_OK;
+  }
   int rc = slot_reserve(h, h->slots[0], h->n_pad, 1);
   if (rc) return rc;
   h->slots[0].kps_host[0] = h->kp;
@@ -1529,13 +1556,15 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
 int64_t sigp_num_blocks(sigp_handle* h) { return h ? h->n_pad / NB : 0; }
 
 int sigp_dist_begin(sigp_handle* h) {
-  if (h && h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "dist_begin: the fp32 engine exposes the fused path only (sigp_fit_predict / batch / predict)");
-
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "dist_begin: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  static AttrOnce diag_attr;
-  if (diag_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  static AttrOnce diag_attr64, diag_attr32;
+  if (h->dtype == SIGP_F64) {
+    if (diag_attr64.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  } else {
+    if (diag_attr32.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  }
   HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
   return sync_slot(h, s);
 }
@@ -1543,6 +1572,10 @@ int sigp_dist_begin(sigp_handle* h) {
 static bool dist_args_ok(sigp_handle* h, int64_t J, int64_t W) {
   return h && h->n > 0 && J >= 0 && W >= 1 && J + W <= h->n_pad / NB;
 }
+static size_t dist_esize(const sigp_handle* h) { return h->dtype == SIGP_F64 ? sizeof(double) : sizeof(float); }
+// the matrix / inverse-diagonal-block buffers the panel loop works on: the fp64 slot or the fp32 engine's
+static char* dist_mat(sigp_handle* h) { return h->dtype == SIGP_F64 ? (char*)h->slots[0].mat : (char*)h->fmat; }
+static char* dist_dinv(sigp_handle* h) { return h->dtype == SIGP_F64 ? (char*)h->slots[0].dinv : (char*)h->fdinv; }
 
 int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W) {
   if (!dist_args_ok(h, J, W)) return -1;
@@ -1559,7 +1592,8 @@ int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info) 
   // mark; later update-stream work waits for the factor
   hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
   if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
-  int rc = dist_panel(h, s, sp, h->n_pad, (int)J, (int)W);
+  int rc = h->dtype == SIGP_F64 ? dist_panel<double>(h, s, s.mat, s.dinv, sp, h->n_pad, (int)J, (int)W)
+                                : dist_panel<float>(h, s, h->fmat, h->fdinv, sp, h->n_pad, (int)J, (int)W);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
   if (h->opt_dist_async) {
@@ -1583,11 +1617,12 @@ int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf) {
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
   hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;      // same stream as the factor that produced the panel
+  const size_t es = dist_esize(h);
   const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
-  double* buf = (double*)dev_buf;
-  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * 8, s.mat + J * NB * ld + J * NB, (size_t)ld * 8, (size_t)wcols * 8, (size_t)rows,
+  char* buf = (char*)dev_buf;
+  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * es, dist_mat(h) + (size_t)(J * NB * ld + J * NB) * es, (size_t)ld * es, (size_t)wcols * es, (size_t)rows,
                              hipMemcpyDeviceToDevice, sp));
-  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, s.dinv + J * NB * NB, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, hipMemcpyAsync(buf + (size_t)rows * wcols * es, dist_dinv(h) + (size_t)(J * NB * NB) * es, (size_t)W * NB * NB * es, hipMemcpyDeviceToDevice, sp));
   HIPCHK(h, hipStreamSynchronize(sp));
   return SIGP_OK;
 }
@@ -1596,13 +1631,14 @@ int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev
   if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_unpack: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
+  const size_t es = dist_esize(h);
   const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
-  const double* buf = (const double*)dev_buf;
+  const char* buf = (const char*)dev_buf;
   // the copy runs on the panel stream: a rank never updates columns it does not own, so a received panel can land
   // while the update stream is still busy with the previous panel's updates; the update stream waits for it
-  HIPCHK(h, hipMemcpy2DAsync(s.mat + J * NB * ld + J * NB, (size_t)ld * 8, buf, (size_t)wcols * 8, (size_t)wcols * 8, (size_t)rows,
+  HIPCHK(h, hipMemcpy2DAsync(dist_mat(h) + (size_t)(J * NB * ld + J * NB) * es, (size_t)ld * es, buf, (size_t)wcols * es, (size_t)wcols * es, (size_t)rows,
                              hipMemcpyDeviceToDevice, s.s_pan));
-  HIPCHK(h, hipMemcpyAsync(s.dinv + J * NB * NB, buf + rows * wcols, (size_t)W * NB * NB * 8, hipMemcpyDeviceToDevice, s.s_pan));
+  HIPCHK(h, hipMemcpyAsync(dist_dinv(h) + (size_t)(J * NB * NB) * es, buf + (size_t)rows * wcols * es, (size_t)W * NB * NB * es, hipMemcpyDeviceToDevice, s.s_pan));
   HIPCHK(h, hipEventRecord(s.ev_pan, s.s_pan));
   HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
   if (h->opt_dist_async) return SIGP_OK;
@@ -1614,7 +1650,8 @@ int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c
   if (!dist_args_ok(h, J, W) || c0 < 0 || c1 < c0 || J + W + c1 > h->n_pad / NB) return fail(h, SIGP_BAD_ARG, "dist_update: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = dist_update(h, s, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
+  int rc = h->dtype == SIGP_F64 ? dist_update<double>(h, s.mat, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1)
+                                : dist_update<float>(h, h->fmat, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
   if (rc) return rc;
   if (h->opt_dist_async) return SIGP_OK;
   return sync_slot(h, s);
@@ -1633,11 +1670,21 @@ int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, do
   if (!h || !out || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_finish: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m);
-  if (rc) return rc;
-  if ((rc = sync_slot(h, s))) return rc;
-  h->fit_res.assign(s.res_host, s.res_host + 512);
-  finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+  int rc;
+  if (h->dtype == SIGP_F32) {
+    // every rank holds the whole fp32 factor: the fp64 refinement runs replicated, no further exchange
+    if (info != 0) {
+      finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+    } else {
+      if ((rc = f32_finish(h, h->kernel_id, h->ell, h->sn_tilde, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, out, mean, var))) return rc;
+      info = (int64_t)out[2];
+    }
+  } else {
+    if ((rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m))) return rc;
+    if ((rc = sync_slot(h, s))) return rc;
+    h->fit_res.assign(s.res_host, s.res_host + 512);
+    finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+  }
   h->built = false;
   h->factored = h->fitted = (info == 0);
   h->sigma_f = out[0]; h->nlml = out[1];

@@ -73,16 +73,20 @@ class DistributedGPR:
     applies the rank-K update to the panels it owns.  After the last panel every rank holds the whole factor and
     the solved ride rows, so sigma_f / nlML / predictions are formed locally with no further collective.
 
+    ``dtype="f32"`` shards the fp32 factorisation of the mixed-precision engine the same way (panels travel as fp32);
+    the fp64 iterative refinement then runs replicated on every rank against its complete copy of the factor.
+
     Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277)."""
 
-    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True):
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True, dtype="f64"):
         from .gpr import GPR
         import torch
         self._torch = torch
         self.rank, self.world, self.dist = int(rank), int(world), dist
         self.W = int(outer_blocks)
         self.lookahead = bool(lookahead)
-        self.gp = GPR(kernel=kernel, device=device)
+        self.dtype = dtype                     # "f32": fp32 factor sharded the same way, fp64 refinement replicated on every rank (configs[4])
+        self.gp = GPR(kernel=kernel, device=device, dtype=dtype)
         self.device = device
         self._bufs = [None, None]
 
@@ -117,7 +121,7 @@ class DistributedGPR:
         nmax = max(nelem) + 1
         for k in range(2):                     # two broadcast buffers: panel p+1 is received while panel p is in use
             if self._bufs[k] is None or self._bufs[k].numel() < nmax:
-                self._bufs[k] = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
+                self._bufs[k] = torch.empty(nmax, dtype=torch.float64 if self.dtype == "f64" else torch.float32, device="cuda:%d" % self.device)
 
         def view(p):
             return self._bufs[p % 2][:nelem[p] + 1]

@@ -377,6 +377,16 @@ for kind, n, d, W in (("rbf", 1100, 8, 2), ("netdiffusion", 700, 12, 1), ("mater
         assert rel(mu3, 2.0 * ref["fmean"]) <= 1e-8, (kind, rank, la)
         Ls.append(L)
     assert np.array_equal(Ls[0], Ls[1]), "look-ahead changed the factor"
+# configs[4] shape at test size: fp32 factor sharded over the ranks, fp64 refinement replicated
+X, y, Xs = O.synthetic_problem(900, 16, 515, m=2)
+ref = O.fit_predict(X, y, Xs, 4.0, 1e-1, kind="matern52", ref_idiom=False)
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+for la in (True, False):
+    with S.DistributedGPR("matern52", rank, world, dist, device=0, outer_blocks=2, lookahead=la, dtype="f32") as dg:
+        dg.fit(X, y, 4.0, 1e-1, Xs=Xs)
+        mu, var = dg.predict(Xs)
+        assert rel(mu, ref["fmean"]) <= 1e-6 and rel(dg.sigma_f_, ref["sigma_f"]) <= 1e-6, (rank, la, rel(mu, ref["fmean"]))
+        assert rel(var, ref["fvar"]) <= 1e-3 and rel(dg.nlml_, ref["nlml"]) <= 1e-5, (rank, la)
 # non-SPD: every rank learns the failing pivot from the broadcast panel and raises like np.linalg.cholesky
 X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
 X[300:350] = X[100:150]

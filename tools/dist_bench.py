@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--outer", type=int, default=8)
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--no-lookahead", action="store_true")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: configs[4] (use --n 32768 --d 32 --kernel matern52 --sn 0.1)")
+    ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern52"])
+    ap.add_argument("--sn", type=float, default=1e-2)
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -43,9 +46,11 @@ def main():
     n, d = args.n, args.d
     X = rng.standard_normal((n, d)); w = rng.standard_normal(d) / np.sqrt(d)
     y = np.sin(X @ w) + 0.1 * rng.standard_normal(n); Xs = rng.standard_normal((1, d))
-    ell, sn = np.sqrt(d), 1e-2
+    if args.dtype == "f32":
+        Xs = Xs[:1]
+    ell, sn = np.sqrt(d), args.sn
     times = []
-    with DistributedGPR("rbf", rank, world, dist, device=local, outer_blocks=args.outer, lookahead=not args.no_lookahead) as dg:
+    with DistributedGPR(args.kernel, rank, world, dist, device=local, outer_blocks=args.outer, lookahead=not args.no_lookahead, dtype=args.dtype) as dg:
         for r in range(args.reps + 1):
             if dist.is_initialized():
                 dist.barrier()
@@ -64,7 +69,7 @@ def main():
         sf, nl = dg.sigma_f_, dg.nlml_
     single = None
     if rank == 0:      # the same fit through the single-GPU entry point, for reference
-        with GPR(kernel="rbf", device=local, outer_blocks=args.outer) as gp:
+        with GPR(kernel=args.kernel, device=local, outer_blocks=args.outer, dtype=args.dtype) as gp:
             for r in range(2):
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 gp.fit(X, y, ell, sn, Xs=Xs)
@@ -72,7 +77,7 @@ def main():
             mu1, var1 = gp.predict(Xs)
         flops = n ** 3 / 3
         best = min(times)
-        print(json.dumps({"workload": "one fit n=%d d=%d fp64 RBF sharded over %d rank(s), 1-D block-cyclic panels of %d x 128 columns" % (n, d, world, args.outer),
+        print(json.dumps({"workload": "one fit n=%d d=%d %s %s sharded over %d rank(s), 1-D block-cyclic panels of %d x 128 columns" % (n, d, args.dtype, args.kernel, world, args.outer),
                           "backend": backend if world > 1 else "none", "lookahead": not args.no_lookahead, "ms_per_fit": [round(1e3 * t, 2) for t in times],
                           "fits_per_s": 1.0 / best, "tflops": flops / best / 1e12, "single_gpu_entry_ms": round(1e3 * single, 2),
                           "mean_rel_vs_single": float(abs(mu[0] - mu1[0]) / abs(mu1[0])), "var_rel_vs_single": float(abs(var[0] - var1[0]) / abs(var1[0])),
