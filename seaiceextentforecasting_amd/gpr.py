@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from .features import laplacian_M, sigma_tilde
+from .features import SigmaEigh, laplacian_M, sigma_tilde
 
 
 class LinAlgError(np.linalg.LinAlgError):
@@ -29,13 +29,17 @@ class LinAlgError(np.linalg.LinAlgError):
 
 class GPR:
     def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None, schedule=None,
-                 panel_mode=None):
+                 panel_mode=None, expm="pade"):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
         if dtype not in ("f64", "f32"):
             raise ValueError("dtype must be 'f64' or 'f32'")
         if dtype == "f32" and kernel == "netdiffusion":
             raise ValueError("the fp32 engine (fp32 factor + fp64 iterative refinement) covers the RBF / Matern kernels only")
+        if expm not in ("pade", "eigh"):
+            raise ValueError("expm must be 'pade' (scipy.linalg.expm per call, the reference's numbers) or 'eigh' (one eigendecomposition per data set)")
+        self._expm = expm              # reference kernel only: how Sigma~ = expm(l M) is formed
+        self._eig = None
         self.dtype = dtype
         self.kernel = kernel
         self._kid = L.KERNEL_IDS[kernel]
@@ -108,9 +112,18 @@ class GPR:
             self._M = laplacian_M(X) if M is None else L.f64(M, 2)
             if self._M.shape != (self.d, self.d):
                 raise ValueError("M must be %dx%d" % (self.d, self.d))
+            self._eig = SigmaEigh(self._M) if self._expm == "eigh" else None     # one eigh per data set
         self._set_ride(Xs)
         self._has_data = True
         self._fitted = False
+
+    def _sigma(self, ell, with_derivative=False):
+        """Sigma~ = expm(l M) (north/June1st.py:264) and, for the MLII gradient, M Sigma~ (:243-244 d Sigma/dl)."""
+        if self._eig is not None:
+            Sig = self._eig.sigma(ell)
+            return (Sig, self._eig.msigma(ell)) if with_derivative else Sig
+        Sig = sigma_tilde(self._M, ell)
+        return (Sig, self._M @ Sig) if with_derivative else Sig
 
     def _set_ride(self, Xs):
         if Xs is None:
@@ -145,7 +158,7 @@ class GPR:
         var = np.zeros(max(m, 1))
         Sig = None
         if self.kernel == "netdiffusion":
-            Sig = L.f64(sigma_tilde(self._M, float(ell)), 2)
+            Sig = L.f64(self._sigma(float(ell)), 2)
             self._Sigma_tilde = Sig
         self._fitted = False
         rc = self._lib.sigp_fit_predict(self._h, self._kid, float(ell), float(sn_tilde), L.ptr(Sig),
@@ -202,8 +215,8 @@ class GPR:
         if self.kernel == "netdiffusion":
             try:
                 with np.errstate(over="raise", invalid="raise"):
-                    Sig = L.f64(sigma_tilde(self._M, ell), 2)
-                    MSig = L.f64(self._M @ Sig, 2)
+                    Sig, MSig = self._sigma(ell, with_derivative=True)
+                    Sig, MSig = L.f64(Sig, 2), L.f64(MSig, 2)
             except (ValueError, OverflowError, FloatingPointError):
                 return inf2
             if not (np.all(np.isfinite(Sig)) and np.all(np.isfinite(MSig))):
@@ -263,7 +276,7 @@ class GPR:
         if not self._has_data:
             raise RuntimeError("build: no data staged")
         if self.kernel == "netdiffusion":
-            Sig = L.f64(sigma_tilde(self._M, float(ell)), 2)
+            Sig = L.f64(self._sigma(float(ell)), 2)
             self._check(self._lib.sigp_kernel_build_from_sigma(self._h, L.ptr(Sig), Sig.shape[1], float(sn_tilde)), "kernel_build")
         else:
             self._check(self._lib.sigp_kernel_build(self._h, self._kid, float(ell), float(sn_tilde)), "kernel_build")

@@ -230,3 +230,28 @@ def test_networks_driver_feeds_the_feature_rules():
     feats = S.select_features(y, ds["anoms"], rule="all_then_pos_p", k=0, pthr=0.05)
     X, Xs = S.design_matrix(feats, False)
     assert X.shape == (T - 1, len(ds["anoms"])) and Xs.shape == (1, len(ds["anoms"]))
+
+
+def test_sigma_eigh_matches_expm_on_golden_laplacians():
+    """one eigendecomposition per data set reproduces expm(l M) and M expm(l M) for the whole l grid,
+    and the captured Sigma~ of the reference's own runs."""
+    from scipy.linalg import expm
+    from seaiceextentforecasting_amd.features import SigmaEigh, LGRID
+    from conftest import load_golden, GOLDEN_NAMES
+    checked = 0
+    for name in GOLDEN_NAMES[:6]:
+        for rec in load_golden(name)["records"][:3]:
+            M = rec["M"]
+            eig = SigmaEigh(M)
+            for ell in list(LGRID[::4]) + [float(rec["ell"])]:
+                if ell * np.abs(M).max() > 50:          # expm itself loses digits beyond this (SURVEY App. C-11)
+                    continue
+                ref = expm(ell * M)
+                assert np.max(np.abs(eig.sigma(ell) - ref)) <= 1e-11 * np.max(np.abs(ref))
+                assert np.max(np.abs(eig.msigma(ell) - M @ ref)) <= 1e-11 * np.max(np.abs(M)) * np.max(np.abs(ref))   # scale of the products summed
+                if ell == float(rec["ell"]):
+                    assert np.max(np.abs(eig.sigma(ell) - rec["Sigma_tilde"])) <= 1e-11 * np.max(np.abs(rec["Sigma_tilde"]))
+                checked += 1
+            S = eig.sigma(1e9)                           # extreme l: still a symmetric stochastic matrix (M has zero row sums)
+            assert np.allclose(S, S.T) and np.allclose(S.sum(axis=1), 1.0, atol=1e-6)
+    assert checked >= 10

@@ -293,6 +293,23 @@ def test_strip_panel_mode_batch_and_failure(S):
         assert rel(r["nlml"][b], ref["nlml"]) <= 1e-9
 
 
+def test_shared_eigendecomposition_for_the_reference_kernel(S):
+    """GPR(expm='eigh') (one eigh of M per data set) gives the same nlML / gradients / predictions as the
+    per-call Pade expm path over an l grid."""
+    X, y, Xs = O.synthetic_problem(300, 10, 5150, m=2)
+    with S.GPR(kernel="netdiffusion") as g0, S.GPR(kernel="netdiffusion", expm="eigh") as g1:
+        g0.set_data(X, y, Xs=Xs); g1.set_data(X, y, Xs=Xs)
+        for ell in (1e-3, 0.05, 1.0, 20.0):
+            for grad in ("ref", "exact"):
+                th = np.log([ell, 1e-2])
+                v0, d0 = g0.nlml(th, grad=grad)
+                v1, d1 = g1.nlml(th, grad=grad)
+                assert abs(v0 - v1) <= 1e-9 * abs(v0) and np.max(np.abs(d0 - d1)) <= 1e-7 * max(np.max(np.abs(d0)), 1e-12)
+            g0.refit(ell, 1e-2); g1.refit(ell, 1e-2)
+            (m0, s0), (m1, s1) = g0.predict(Xs), g1.predict(Xs)
+            assert rel(m1, m0) <= TOL_PRED and rel(s1, s0) <= TOL_PRED
+
+
 def test_full_size_properties_n4096(S):
     """BASELINE configs[1] (n=4096, d=8 RBF): oracle comparison + size-independent identities."""
     n, d = 4096, 8
