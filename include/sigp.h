@@ -153,7 +153,17 @@ int sigp_profile(sigp_handle* h, int enable);
 int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* launches, double* flops,
                      double* bytes);
 int sigp_profile_reset(sigp_handle* h);
-/* tuning knobs (block widths in units of 128 columns, look-ahead on/off); returns SIGP_BAD_ARG if invalid */
+/* tuning knobs; returns SIGP_BAD_ARG for an unknown name or an invalid value.  Defaults in brackets.
+ *   outer_blocks [8]      outer panel width in 128-column blocks (K of the trailing update = 128 x this)
+ *   lookahead [1]         factor the next panel on the panel stream while the trailing update runs
+ *   schedule [0]          0 right-looking outer panels, 1 left-looking (same factor bit for bit)
+ *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
+ *   panel_ll [0]          panels up to this width are factored left-looking inside
+ *   group [8]             fits factorised in lockstep per launch (batch path)
+ *   small_tile_threshold [320], trsm128_threshold [256]   tile-shape switches by tile count
+ *   refine_iters [3]      fp32 engine: fp64 refinement steps
+ *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack return without a host sync (see sigp_dist_sync)
+ *   pan_priority, diag_prio, syrk_v2, patch, reserve_cus, host_timing   measurement switches */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus
