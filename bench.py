@@ -195,25 +195,35 @@ def main():
             ncpu = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [ncpu])
         except Exception:
             pass
+        # the sample is the FIRST TIMED STEP of the run above: data set W % years, hyper-parameters of step W
         nb = n if n <= 8192 else 8192
-        Xc, yc, Xsc = O.synthetic_problem(nb, d, 20240002, m=1)
+        ds0 = W % years
+        if nb == n:
+            Xc, yc, Xsc = Xb[ds0], yb[ds0], Xsb[ds0]
+        else:
+            Xc, yc, Xsc = O.synthetic_problem(nb, d, 20240002, m=1)
+        ell0, sn0 = float(ell[W]), float(sn[W])
         t0 = time.perf_counter()
-        ref = O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=True)
+        ref = O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=True)
         tc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
-                               "sample": "1 fit, n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / SciPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d, CPU: %s)" % (nb, d, np.__version__, scipy.__version__, ncpu, os.cpu_count(), cpu_model),
+                               "sample": "1 fit (the first timed step: year %d, l=%.4g, sn~=%.3g), n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / SciPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d, CPU: %s)" % (ds0, ell0, sn0, nb, d, np.__version__, scipy.__version__, ncpu, os.cpu_count(), cpu_model),
                                "seconds": tc}
         t0 = time.perf_counter()
-        O.fit_predict(Xc, yc, Xsc, grid_point(0, d)[0], grid_point(0, d)[1], kind="rbf", ref_idiom=False)
+        O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=False)
         tb = time.perf_counter() - t0
         out["cpu_baseline_best_practice"] = {"value": 1.0 / tb, "unit": "fits/s", "cores": ncpu, "kind": "port", "seconds": tb,
                                              "sample": "1 fit, same inputs, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)"}
-        if nb == n:   # parity of the timed configuration against the CPU path on the same inputs
+        if nb == n:   # parity of the timed configuration against the CPU path on the same inputs: the timed lockstep batch's own
+            # result for that step, and the same fit through the single-fit entry point
             with GPR(kernel="rbf", device=local) as g2:
-                g2.fit(Xc, yc, grid_point(0, d)[0], grid_point(0, d)[1], Xs=Xsc)
+                g2.fit(Xc, yc, ell0, sn0, Xs=Xsc)
                 mu, var = g2.predict(Xsc)
-            out["parity"] = {"mean_rel": float(abs(mu[0] - ref["fmean"][0]) / abs(ref["fmean"][0])),
-                             "var_rel": float(abs(var[0] - ref["fvar"][0]) / abs(ref["fvar"][0])), "tolerance": 1e-8}
+            relf = lambda a, b: float(abs(a - b) / abs(b))
+            out["parity"] = {"batch_step0_mean_rel": relf(r["mean"][0, 0], ref["fmean"][0]), "batch_step0_var_rel": relf(r["var"][0, 0], ref["fvar"][0]),
+                             "batch_step0_nlml_rel": relf(r["nlml"][0], ref["nlml"]),
+                             "single_fit_mean_rel": relf(mu[0], ref["fmean"][0]), "single_fit_var_rel": relf(var[0], ref["fvar"][0]), "tolerance": 1e-08}
+            assert max(out["parity"]["batch_step0_mean_rel"], out["parity"]["batch_step0_var_rel"]) <= 1e-8, out["parity"]
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
