@@ -5,10 +5,14 @@
 // One 256-thread workgroup (the step is a latency chain, not throughput work).  The block lives in LDS
 // ([128][130] doubles: pitch 130 keeps the 8-byte MFMA fragment reads conflict free).  It is processed in
 // 16-column steps:
-//   B1  16x16 diagonal factorisation by ONE wave, rows in registers, pivots and column entries broadcast with DPP
-//       row_newbcast (wavefront shuffles in one VALU instruction: no SGPR or LDS round trips, no barriers in the step);
+//   B1  16x16 diagonal factorisation by ONE wave, rows in registers, pivots broadcast with v_readlane
+//       (wavefront shuffles, no LDS round trips, no barriers inside the step);
 //   B2  16-wide triangular solve of the rows below, one thread per row, L11 broadcast from LDS;
 //   B3  rank-16 update of the remaining lower tiles on v_mfma_f64_16x16x4_f64.
+// Register budget: the kernel must stay at <= 128 VGPRs (121 now).  Its 8 waves then take 2 x 128 of a SIMD's 512
+// registers and fit beside ONE resident wave of the trailing-update kernel (256 VGPRs); a 220-VGPR build (measured with a
+// DPP row_newbcast pivot loop, 7 % faster on an idle GPU) has to wait for BOTH update workgroups of a CU to finish:
+// 1.06 ms instead of 0.23 ms per launch in lockstep batches, -2 % fits/s.  Check `.vgpr_count` after touching it.
 // The inverse is formed with the in-place blocked lower-triangular recurrence (LAPACK dtrtri shape,
 // last block column first), again with MFMA for the block products.
 #pragma once
@@ -36,54 +40,6 @@ __device__ inline float readlane_t(float x, int l) { return __int_as_float(__bui
 __device__ inline double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
 __device__ inline float rsq_seed(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BSZ; }   // bj <= bi
-
-// lane C of every 16-lane row to all lanes of that row in ONE VALU instruction (DPP row_newbcast; v_mov_b64_dpp for
-// doubles on gfx90a+): no SGPR round trip and none of the v_readlane -> VALU hazard slots
-template <typename T, int C>
-__device__ inline T row_bcast(T v) { return __builtin_amdgcn_update_dpp(v, v, 0x150 + C, 0xf, 0xf, true); }
-
-// B1: 16x16 Cholesky with lane (mod 16) = row, the 16 row entries in registers.  Pivot J: broadcast r[J] of lane J,
-// 1/sqrt by the hardware seed + two Goldschmidt steps, scale column J, rank-1 update of columns J+1..15 with the
-// column entries broadcast lane by lane.  Template recursion because the DPP lane selector is an immediate.
-template <typename T, int J, int C>
-struct B1Update {
-  // r[C] -= l_iJ l_CJ.  (Measured and dropped: the update written as (a_iJ / d_J) a_CJ with a Newton reciprocal, which
-  // takes the square root off the pivot-to-pivot dependency chain, is 10 % SLOWER -- the wave is issue-bound.)
-  __device__ static inline void run(T (&r)[16], T lij) {
-    r[C] = fma(-lij, row_bcast<T, C>(lij), r[C]);
-    B1Update<T, J, C + 1>::run(r, lij);
-  }
-};
-template <typename T, int J>
-struct B1Update<T, J, 16> { __device__ static inline void run(T (&)[16], T) {} };
-
-template <typename T, int J>
-struct B1Pivot {
-  __device__ static inline void run(T (&r)[16], int lr, int lane, int* info, int pivot_index_base, T* dinv_out) {
-    T dj = row_bcast<T, J>(r[J]);
-    if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
-      if (lane == 0 && *info == 0) *info = pivot_index_base + J + 1;
-      dj = (T)1;
-    }
-    const T aJ = r[J];
-    const T y0 = rsq_seed(dj);
-    T g = dj * y0, hh = (T)0.5 * y0;
-    T e = fma(-hh, g, (T)0.5);
-    g = fma(g, e, g); hh = fma(hh, e, hh);
-    e = fma(-hh, g, (T)0.5);
-    g = fma(g, e, g); hh = fma(hh, e, hh);
-    const T e2 = fma(-g, g, dj);
-    const T sq = fma(e2, hh, g);     // sqrt(dj)
-    const T inv = hh + hh;           // 1/sqrt(dj)
-    const T lij = (lr == J) ? sq : aJ * inv;
-    r[J] = lij;
-    B1Update<T, J, J + 1>::run(r, lij);
-    if (lane == 0) dinv_out[J] = inv;
-    B1Pivot<T, J + 1>::run(r, lr, lane, info, pivot_index_base, dinv_out);
-  }
-};
-template <typename T>
-struct B1Pivot<T, 16> { __device__ static inline void run(T (&)[16], int, int, int*, int, T*) {} };
 
 // A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace whose
 // strictly-upper part is zero (zeroed once at allocation, never written here);
@@ -122,38 +78,34 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
   for (int jb = 0; jb < 8; ++jb) {
     T* Sjj = S + dblk(jb, jb);
     if (wave == 0 && !(skip & 1)) {
-      // B1: 16x16 Cholesky; lane i (mod 16) holds row i (the four 16-lane rows of the wave work on replicas)
+      // B1: 16x16 Cholesky; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by v_rsq_f64 + Goldschmidt
       T r[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
-      if (skip & 64) {   // (A/B switch) v_readlane formulation
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          T dj = readlane_t(r[j], j);
-          if (!(dj > (T)0)) {
-            if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
-            dj = (T)1;
-          }
-          const T y0 = rsq_seed(dj);
-          T g = dj * y0, hh = (T)0.5 * y0;
-          T e = fma(-hh, g, (T)0.5);
-          g = fma(g, e, g); hh = fma(hh, e, hh);
-          e = fma(-hh, g, (T)0.5);
-          g = fma(g, e, g); hh = fma(hh, e, hh);
-          const T e2 = fma(-g, g, dj);
-          const T s = fma(e2, hh, g);
-          const T inv = hh + hh;
-          const T lij = (lr == j) ? s : r[j] * inv;
-          r[j] = lij;
-#pragma unroll
-          for (int c = j + 1; c < 16; ++c) {
-            const T lcj = readlane_t(lij, c);
-            r[c] = fma(-lij, lcj, r[c]);
-          }
-          if (lane == 0) dinv[jb * 16 + j] = inv;
+      for (int j = 0; j < 16; ++j) {
+        T dj = readlane_t(r[j], j);
+        if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
+          if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
+          dj = (T)1;
         }
-      } else {
-        B1Pivot<T, 0>::run(r, lr, lane, info, pivot_base + jb * 16, dinv + jb * 16);
+        const T y0 = rsq_seed(dj);
+        T g = dj * y0, hh = (T)0.5 * y0;
+        T e = fma(-hh, g, (T)0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        e = fma(-hh, g, (T)0.5);
+        g = fma(g, e, g); hh = fma(hh, e, hh);
+        const T e2 = fma(-g, g, dj);
+        const T s = fma(e2, hh, g);      // sqrt(dj)
+        const T inv = hh + hh;           // 1/sqrt(dj)
+        const T lij = (lr == j) ? s : r[j] * inv;
+        r[j] = lij;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          const T lcj = readlane_t(lij, c);
+          r[c] = fma(-lij, lcj, r[c]);
+        }
+        if (lane == 0) dinv[jb * 16 + j] = inv;
       }
       if (lane < 16) {
 #pragma unroll

@@ -32,12 +32,12 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
 template <typename T, bool SET>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
-                                             long ldc, int K, int dbg, T* As, T* Bs, unsigned long long* phase = nullptr) {
+                                             long ldc, int K, int dbg, T* As, T* Bs, bool stamp, unsigned long long& ph0, unsigned long long& ph1) {
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v16_t v16_t;
   constexpr int KTe = N_::KT, NE = N_::NE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -78,7 +78,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   v16_t a0[4], b0[4], a1[4], b1[4];
   SY_ISSUE(0, 0);
   __syncthreads();
-  if (phase) phase[0] = __builtin_amdgcn_s_memtime();   // C tile and first K-slice have landed
+  if (stamp) ph0 = __builtin_amdgcn_s_memtime();   // C tile and first K-slice have landed
   if (nst > 1) SY_ISSUE(KTe, 1);
 #pragma unroll
   for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
@@ -125,7 +125,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef SY_ISSUE
-  if (phase) phase[1] = __builtin_amdgcn_s_memtime();   // K loop issued
+  if (stamp) ph1 = __builtin_amdgcn_s_memtime();   // K loop issued
 
   if (!(dbg & 16) || acc[0][0][0] == (T)12345.678) {   // dbg 16: timing ablation without the C store
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* As = (T*)smem_raw;                 // [2][128][KT]
   T* Bs = As + 2 * SY_T * KTe;          // [2][128][KT]
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   int bi, bj;
   if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
@@ -153,13 +153,13 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
   unsigned long long st_c0 = 0, st_r0 = 0;
   if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-  unsigned long long ph[2] = {0, 0};
-  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, g.stamp ? ph : nullptr);
+  unsigned long long ph0 = 0, ph1 = 0;
+  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, g.stamp != nullptr, ph0, ph1);
   if (g.stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
     __builtin_amdgcn_s_waitcnt(0);
     if (tid == 0) {
       unsigned long long* o = g.stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
-      o[0] = ph[0] - st_c0; o[1] = ph[1] - ph[0]; o[2] = __builtin_amdgcn_s_memtime() - ph[1];
+      o[0] = ph0 - st_c0; o[1] = ph1 - ph0; o[2] = __builtin_amdgcn_s_memtime() - ph1;
     }
   }
   if (g.stamp && tid == 0) {
@@ -192,14 +192,15 @@ __global__ __launch_bounds__(256, 2) void panel_strip_kernel(StripArgsT<T> g) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* As = (T*)smem_raw;
   T* Bs = As + 2 * SY_T * KTe;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const long bz = blockIdx.y;
+  unsigned long long ph0 = 0, ph1 = 0;
   T* strip = g.M + bz * g.sM + (long)(g.rb0 + blockIdx.x) * SY_T * g.ld + (long)g.J * SY_T;
   const T* Mt = g.Mt + bz * g.sMt;
   for (int j = 0; j < g.Wp; ++j) {
     syrk128_tile<T, true>(strip, g.ld, Mt + (long)j * SY_T * g.ldm, g.ldm, strip + (long)(wm * 64) * g.ld + (long)j * SY_T + wn * 64, g.ld,
-                          SY_T * (j + 1), 0, As, Bs);
+                          SY_T * (j + 1), 0, As, Bs, false, ph0, ph1);
     // X_j is the A operand of the next column.  Producer and consumer are the same workgroup (one CU, one L1/L2
     // path), so workgroup scope is enough: __syncthreads() waits for this wave's stores (vmcnt) and for everyone's
     // fragment reads of this tile before the next tile's DMA refills the LDS buffers.  (An agent-scope fence here
