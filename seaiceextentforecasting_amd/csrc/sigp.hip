@@ -1840,19 +1840,22 @@ int sigp_debug_mfma_peak(sigp_handle* h, int blocks, int iters, double* tflops, 
 }
 
 // time the lower-tile update C -= P P^T (128x128 tiles) on a synthetic (rt*128) x K panel, tile walk `patch`
-int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
+}  // extern "C" (templates need C++ linkage)
+
+template <typename Real>
+static int debug_time_syrk_t(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
   if (!h || rt < 1 || K < 16 || reps < 1) return SIGP_BAD_ARG;
   HIPCHK(h, hipSetDevice(h->device));
   const long n = (long)rt * NB, ldp = K, ldc = n;
-  double *P, *Cm;
-  HIPCHK(h, hipMalloc((void**)&P, (size_t)n * K * 8)); HIPCHK(h, hipMalloc((void**)&Cm, (size_t)n * n * 8));
-  HIPCHK(h, hipMemset(Cm, 0, (size_t)n * n * 8));
-  std::vector<double> hp((size_t)n * K);
-  for (size_t i = 0; i < hp.size(); ++i) hp[i] = 1e-3 * (double)((i * 2654435761u) % 1000) - 0.5;
-  HIPCHK(h, hipMemcpy(P, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
+  Real *P, *Cm;
+  HIPCHK(h, hipMalloc((void**)&P, (size_t)n * K * sizeof(Real))); HIPCHK(h, hipMalloc((void**)&Cm, (size_t)n * n * sizeof(Real)));
+  HIPCHK(h, hipMemset(Cm, 0, (size_t)n * n * sizeof(Real)));
+  std::vector<Real> hp((size_t)n * K);
+  for (size_t i = 0; i < hp.size(); ++i) hp[i] = (Real)(1e-3 * (double)((i * 2654435761u) % 1000) - 0.5);
+  HIPCHK(h, hipMemcpy(P, hp.data(), hp.size() * sizeof(Real), hipMemcpyHostToDevice));
   hipStream_t st = h->slots[0].s_pan;
   hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  GemmArgs g{};
+  GemmArgsT<Real> g{};
   g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp; g.C = Cm; g.ldc = ldc; g.K = K; g.r0 = 0; g.r1 = rt; g.c0 = 0; g.c1 = rt; g.lower = 1; g.patch = patch; g.dbg = dbg;
   unsigned long long* stamp = nullptr;
   const int ngrid = gemm_grid_size(0, rt, 0, rt, 1, patch);
@@ -1861,7 +1864,7 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
   double tot = 0;
   for (int r = 0; r < reps + 2; ++r) {
     HIPCHK(h, hipEventRecord(e0, st));
-    int rc = small == 1 ? launch_gemm_cfg<64, 64, 2, 2, GEMM_SUB, false>(h, st, g) : small == 2 ? launch_syrk128(h, st, g) : launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
+    int rc = small == 1 ? launch_gemm_cfg<Real, 64, 64, 2, 2, GEMM_SUB, false>(h, st, g) : small == 2 ? launch_syrk128_t<Real, false>(h, st, g) : launch_gemm_cfg<Real, 128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
     if (rc) return rc;
     HIPCHK(h, hipEventRecord(e1, st));
     HIPCHK(h, hipStreamSynchronize(st));
@@ -1887,6 +1890,14 @@ int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, in
   if (tflops) *tflops = nt * 2.0 * NB * NB * K / (tot / reps * 1e-3) / 1e12;
   (void)hipFree(P); (void)hipFree(Cm); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   return SIGP_OK;
+}
+
+extern "C" {
+
+// small: 0 generic 128-tile kernel, 1 generic 64-tile kernel, 2 syrk128_kernel; +16: the fp32 instantiation
+int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
+  if (small & 16) return debug_time_syrk_t<float>(h, rt, K, patch, small & 15, reps, ms_avg, tflops, dbg, clock_ghz);
+  return debug_time_syrk_t<double>(h, rt, K, patch, small, reps, ms_avg, tflops, dbg, clock_ghz);
 }
 
 // do independent small kernels on different streams of this handle overlap?  returns wall ms for nstreams x reps launches

@@ -28,6 +28,12 @@ elif mode == "ablate2":
         for dbg in (0, 1, 4, 5, 2, 3, 7, 24, 25, 31, 0):
             lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 4, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
             print("%2d %4d %3d | %6.3f  %6.1f   %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
+elif mode == "f32":
+    # the fp32 instantiation (small = 2 + 16): dbg 1 no DMA, 2 no fragment reads, 8+16 no C traffic
+    for rt, K in ((127, 1024), (127, 4096)):
+        for dbg in (0, 1, 2, 3, 24, 256):
+            lib.sigp_debug_time_syrk(h, rt, K, 0, 2 + 16, 3, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
+            print("fp32 %3d %4d dbg %3d | %6.3f ms  %6.1f TFLOP/s  %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
 elif mode == "phases":
     # dbg 256: in-kernel cycle counts of the three phases of a tile (printed on stderr by the debug entry)
     for rt, K in ((127, 1024), (127, 512), (127, 128), (90, 4096)):
