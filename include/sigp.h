@@ -163,7 +163,7 @@ int sigp_profile_reset(sigp_handle* h);
  *   small_tile_threshold [320], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps
  *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack return without a host sync (see sigp_dist_sync)
- *   pan_priority, diag_prio, syrk_v2, patch, reserve_cus, host_timing   measurement switches */
+ *   pan_priority, diag_prio, syrk_v2, patch, reserve_cus, c_dma, host_timing   measurement switches */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

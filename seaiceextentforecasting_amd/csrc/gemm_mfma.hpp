@@ -33,6 +33,9 @@ template <> struct Num<double> {
   static constexpr int LDP = 18;      // LDS pitch (elements) of a [row][k] image: conflict-free 8-byte fragment reads
   __device__ static inline acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
   __device__ static inline int drow(int lq, int r) { return lq + 4 * r; }
+  // 16-byte-chunk swizzle of row R of a [rows][128] C image in LDS: a 32-lane ds_read_b64 pass sees lq = 0,1 (rows R, R+1)
+  // x 16 consecutive doubles; shifting odd rows by 128 B makes the two rows cover all 64 banks once
+  __device__ static inline int cswz(int R) { return (R & 1) << 3; }
 };
 template <> struct Num<float> {
   typedef f4 acc_t;  typedef f4 v16_t;  typedef f2 v2_t;
@@ -41,6 +44,8 @@ template <> struct Num<float> {
   static constexpr int LDP = 36;      // 144-byte rows (16-byte aligned); 4-byte fragment reads are 2-way conflicted
   __device__ static inline acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
   __device__ static inline int drow(int lq, int r) { return 4 * lq + r; }
+  // fp32: a 64-lane ds_read_b32 sees 4 rows (R, R+4, R+8, R+12) x 16 consecutive floats (64 B): shift by 64 B per row group
+  __device__ static inline int cswz(int R) { return ((R >> 2) & 3) << 2; }
 };
 
 constexpr int KT = Num<double>::KT;   // (fp64 names kept for the fp64-only call sites)

@@ -98,6 +98,7 @@ struct sigp_handle {
   int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
                              // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
   int opt_strip_min = 512;
+  int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
@@ -313,6 +314,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
+    if (h->opt_c_dma) g.dbg |= 128;
     return launch_syrk128_t<T, false>(h, st, g);
   }
   if (nt >= h->opt_small_tiles) {
@@ -890,6 +892,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "c_dma")) { h->opt_c_dma = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }

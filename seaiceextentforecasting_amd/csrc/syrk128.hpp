@@ -42,12 +42,53 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   const int lr = lane & 15, lq = lane >> 4;
 
   acc_t acc[4][4];
+  if (SET || (dbg & 8)) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = (SET || (dbg & 8)) ? (T)0 : -Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr];
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+  } else if (!(dbg & 128)) {   // accumulator-layout loads straight from global: 64 8-byte loads per lane
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = -Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr];
+  } else {
+    // (dbg 128) acc = -C through LDS: the C tile comes in by LDS-DMA (16 bytes per lane, one wave-instruction per 1 KiB)
+    // in two halves of 64 rows -- the A/B staging buffers are idle before the K loop -- and each wave picks its
+    // accumulator fragments out of LDS
+    constexpr int CPR = SY_T / NE;                 // 16-byte chunks per C row (64 fp64 / 32 fp32)
+    constexpr int RPI = 64 / CPR;                  // rows per wave-instruction (1 / 2)
+    T* Cs = As;                                    // [64][128] image (fp64: all 64 KiB of As+Bs)
+    const T* Ctile = Cw - (long)(wm * 64) * ldc - wn * 64;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (hh) __syncthreads();                     // fragment reads of the first half are done
+#pragma unroll
+      for (int q = 0; q < 16 / RPI; ++q) {
+        const int R0 = wave * 16 + q * RPI;        // first row of this instruction inside the half
+        const int R = R0 + (lane / CPR), ch = lane % CPR;
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Ctile + (long)(hh * 64 + R) * ldc + ((ch ^ N_::cswz(R)) * NE)),
+                                         (lds_ptr_t)(Cs + R0 * SY_T), 16, 0, 0);
+      }
+      __syncthreads();
+      if (wm == hh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int R = i * 16 + N_::drow(lq, r), col = wn * 64 + j * 16 + lr;
+              acc[i][j][r] = -Cs[R * SY_T + (((col / NE) ^ N_::cswz(R)) * NE) + (col % NE)];
+            }
+      }
+    }
+    __syncthreads();                               // LDS is free for the A/B pipeline
+  }
 
   // DMA coordinates: per wave-instruction 8 rows x 128 B; lane -> (row = lane>>3, slot' = lane&7)
   const int drow_ = wave * 8 + (lane >> 3);                  // + 32*p

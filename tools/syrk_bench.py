@@ -34,6 +34,12 @@ elif mode == "f32":
         for dbg in (0, 1, 2, 3, 24, 256):
             lib.sigp_debug_time_syrk(h, rt, K, 0, 2 + 16, 3, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
             print("fp32 %3d %4d dbg %3d | %6.3f ms  %6.1f TFLOP/s  %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
+elif mode == "cdma":
+    # dbg 128: C-tile prologue through LDS-DMA instead of 64 accumulator-layout loads per lane
+    for rt, K in ((127, 1024), (127, 512), (127, 256)):
+        for dbg in (256, 256 + 128, 256, 256 + 128):
+            lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 3, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
+            print("%3d %4d dbg %4d | %6.3f ms  %6.1f TFLOP/s  %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
 elif mode == "phases":
     # dbg 256: in-kernel cycle counts of the three phases of a tile (printed on stderr by the debug entry)
     for rt, K in ((127, 1024), (127, 512), (127, 128), (90, 4096)):
