@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 40 --no-profile > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err || exit 1
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err || exit 1
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 40 --warmup 40 --no-profile > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "mfma pmc pass failed"
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "mfma pmc pass failed"
 ls -R $OUT | head -40

@@ -3,7 +3,7 @@ import json, sys
 import pandas as pd
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 base = "gpurun_out/%s/" % rnd
-out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 40 --warmup 40 --no-profile  (one pass per counter set)",
+out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile  (one pass per counter set)",
        "kernel": "sigp::syrk128_kernel<double, false>", "notes": []}
 sel = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<double, false>", regex=False)]
 fe = sel(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
