@@ -276,6 +276,29 @@ def test_strip_panel_mode_matches_oracle(S, kind, n, W):
     assert np.array_equal(Ls[0], Ls[1])
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_strip_vs_recursive_random_shapes(S, seed):
+    """Random (n, d, m, W, group) -- strips forced -- against the recursive path on the same lockstep batch."""
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(130, 2600)); d = int(rng.integers(1, 20)); m = int(rng.integers(0, 6))
+    W = int(rng.choice([2, 3, 4, 6, 8, 16])); B = int(rng.integers(1, 5))
+    kind = ["rbf", "matern52"][seed % 2]
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, max(m, 1), d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 100 * seed + b, m=max(m, 1))
+    Xs_arg = Xsb[:, :m] if m > 0 else None
+    ell = np.sqrt(d) * rng.uniform(0.5, 2.0, B); sn = 10.0 ** rng.uniform(-3, 0, B)
+    res = {}
+    for mode in ("recursive", "strips"):
+        with S.GPR(kernel=kind, outer_blocks=W, panel_mode=mode) as gp:
+            res[mode] = gp.fit_batch(Xb, yb, Xs_arg, ell, sn, concurrency=1, group=B)
+    a, b_ = res["recursive"], res["strips"]
+    assert np.all(a["info"] == 0) and np.all(b_["info"] == 0)
+    assert rel(b_["nlml"], a["nlml"]) <= 1e-10 and rel(b_["sigma_f"], a["sigma_f"]) <= 1e-10
+    if m > 0:
+        assert rel(b_["mean"], a["mean"]) <= TOL_PRED and rel(b_["var"], a["var"]) <= TOL_PRED
+
+
 def test_strip_panel_mode_batch_and_failure(S):
     """Lockstep batch in strips mode == sequential default-mode fits to parity tolerance; a non-SPD member reports its pivot."""
     n, d, B = 700, 6, 5
