@@ -5,14 +5,22 @@ A step = one pass of the hot path over one batch of the BASELINE.json configs[2]
 "years" (n=8192, d=8, fp64 RBF) at ONE hyper-parameter grid point, i.e. 40 GP fits factorised in lockstep:
 kernel-matrix build -> blocked Cholesky (with y and the test point riding along) -> sigma_f, nlML, predictive
 mean/variance at m=1 for each.  The metric stays GP fits/sec (= 40 x steps / time).  Inputs (the years' X, y, Xs)
-are resident in HBM before the timed region.  N>1: ranks hold different years (independent fits, no data-path
-collective) -> weak scaling; value = total fits / max-over-ranks time.
+are resident in HBM before the timed region.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 8192] [--d 8] [--concurrency C]
+N > 1 (one process per GPU, RCCL for the barrier / max-reduce only -- independent fits need no data-path collective):
+  --scaling weak   (default) every rank holds its own 40 years and runs the same number of steps: per-GPU work fixed
+  --scaling strong the fixed job (steps x 40 fits) is dealt round-robin over the ranks (a rank's lockstep groups then mix
+                   years and grid points)
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a `torch.distributed.run` child,
+spawned before this process touches the GPU); under torchrun WORLD_SIZE must equal --gpus.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--grid smoke|full] [--scaling weak|strong] [--n 8192] [--d 8]
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,7 +30,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per HIP 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F64_MFMA_TFLOPS = 78.6   # MI355X dense fp64 matrix peak (= fp64 vector peak), SURVEY.md 8(d)
+PEAK_F64_MFMA_TFLOPS = 78.6    # MI355X dense fp64 matrix peak (= fp64 vector peak), SURVEY.md 8(d)
+PEAK_F32_MFMA_TFLOPS = 157.3   # dense fp32 matrix peak
 
 
 def synthetic_problem(n, d, seed, m=1):
@@ -35,11 +44,43 @@ def synthetic_problem(n, d, seed, m=1):
     return X, y, Xs
 
 
-def grid_point(i, d):
-    """Step i's hyper-parameters: the 4x4 'smoke' grid of SURVEY 8(d) around l = sqrt(d), sn~ = 1e-2."""
-    ells = np.sqrt(d) * np.logspace(-0.5, 0.5, 4)
-    sns = np.logspace(-3, -1, 4)
-    return ells[i % 4], sns[(i // 4) % 4]
+def grid_axes(d, which):
+    """SURVEY 8(d) hyper-parameter grid of configs[2]: l in sqrt(d) logspace(-1, 1, G1), sn~ in logspace(-3, 1, G2);
+    full = 20 x 20 (mirrors the reference's north/June1st.py:210-211 axes), smoke = 4 x 4 over the same ranges."""
+    g = 20 if which == "full" else 4
+    return np.sqrt(d) * np.logspace(-1, 1, g), np.logspace(-3, 1, g)
+
+
+def grid_point(i, d, which="smoke"):
+    """Step i's hyper-parameters: the grid is walked l-fastest and wraps."""
+    ells, sns = grid_axes(d, which)
+    return ells[i % len(ells)], sns[(i // len(ells)) % len(sns)]
+
+
+def flops_per_fit(n, d, m=1):
+    """SURVEY 8(d) F(n, d, m): potrf + lower-triangle distance build + two TRSV + predict."""
+    return n ** 3 / 3 + n ** 2 / 2 + n / 6 + n * n * d + n * n / 2 + 2 * n * n + m * (2 * n * d + n * n + 4 * n)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as a child `torch.distributed.run` and pass its exit
+    code on.  Nothing in this process has touched the GPU yet (device_count() does not initialise it)."""
+    import torch
+    backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; one rank per GPU over RCCL needs %d "
+                         "(SIGP_BENCH_BACKEND=gloo lets ranks share a GPU for rehearsal)" % (args.gpus, ndev, args.gpus))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -49,7 +90,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--years", type=int, default=40, help="distinct synthetic data sets (retrospective years) resident per rank")
+    ap.add_argument("--years", type=int, default=40, help="distinct synthetic data sets (retrospective years) of the job")
+    ap.add_argument("--grid", choices=["smoke", "full"], default="smoke", help="hyper-parameter grid the steps walk: 4x4 or 20x20 over the SURVEY 8(d) ranges")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--concurrency", type=int, default=1, help="lockstep groups in flight")
     ap.add_argument("--group", type=int, default=40, help="fits factorised in lockstep per launch")
     ap.add_argument("--outer", type=int, default=8, help="outer panel width in 128-column blocks (K of the trailing update = 128*outer)")
@@ -57,17 +100,28 @@ def main():
     ap.add_argument("--host-timing", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=1, help="timed CPU repetitions at n=8192 (48 s each in the reference idiom; n=64 and n=4096 always run 1 warm-up + 3)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra records (other configs, MLII, reference-kernel grid)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                                        # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ...)" % (args.gpus, world, args.gpus, args.gpus))
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     dist = None
     backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()
     if world > 1:
         import torch.distributed as dist
@@ -81,9 +135,34 @@ def main():
 
     n, d, m = args.n, args.d, 1
     years = max(1, args.years)
-    Xb = np.zeros((years, n, d)); yb = np.zeros((years, n)); Xsb = np.zeros((years, m, d))
-    for b in range(years):
-        Xb[b], yb[b], Xsb[b] = synthetic_problem(n, d, 20240002 + 1000 * rank + b, m=m)
+    G = max(1, args.group)                   # fits per step
+    total_steps = args.warmup + args.steps
+    # ---- which fits this rank runs.  Global fit i (step s = i // G) = year i % years at grid point s. -----------------
+    if args.scaling == "weak" or world == 1:
+        # every rank: its own `years` data sets (different seeds), all steps
+        my_years = list(range(years))
+        seeds = [20240002 + 1000 * rank + b for b in my_years]
+        my_fits = np.arange(total_steps * G)
+        fit_step = my_fits // G
+        n_warm = args.warmup * G
+    else:
+        # strong: the fixed job of steps x G fits is dealt round-robin; the warm-up steps are dealt the same way
+        all_fits = np.arange(total_steps * G)
+        mine = all_fits[rank::world]
+        fit_step = mine // G
+        yr = mine % years
+        period = len(np.unique(yr))          # the rank's year sequence is periodic (years / gcd(world, years))
+        assert np.array_equal(yr, np.tile(yr[:period], len(yr) // period + 1)[:len(yr)])
+        my_years = [int(v) for v in yr[:period]]
+        seeds = [20240002 + b for b in my_years]
+        my_fits = mine
+        n_warm = int(np.sum(fit_step < args.warmup))
+    Xb = np.zeros((len(my_years), n, d)); yb = np.zeros((len(my_years), n)); Xsb = np.zeros((len(my_years), m, d))
+    for j, sd in enumerate(seeds):
+        Xb[j], yb[j], Xsb[j] = synthetic_problem(n, d, sd, m=m)
+    ell = np.array([grid_point(int(s), d, args.grid)[0] for s in fit_step])
+    sn = np.array([grid_point(int(s), d, args.grid)[1] for s in fit_step])
+    K, W = len(my_fits) - n_warm, n_warm    # this rank's timed / warm-up FITS
 
     gp = GPR(kernel="rbf", device=local, outer_blocks=args.outer, reserve_cus=args.reserve_cus)
     for o in args.opt:
@@ -91,11 +170,7 @@ def main():
         gp.set_option(k, int(v))
     if args.host_timing:
         gp.set_option("host_timing", 1)
-    G = max(1, args.group)                   # fits per step
-    K, W = args.steps * G, args.warmup * G   # timed / warm-up FITS; step s = fits [s*G, (s+1)*G) = every year at grid point s
-    ell = np.array([grid_point(i // G, d)[0] for i in range(W + K)])
-    sn = np.array([grid_point(i // G, d)[1] for i in range(W + K)])
-    # upload + slot allocation (outside the timed region), then W untimed warm-up steps
+    # upload + slot allocation (outside the timed region), then the untimed warm-up steps
     gp.upload_batch(Xb, yb, Xsb, group=args.group, concurrency=args.concurrency)
     if W > 0:
         r = gp.run_batch(0, W, ell[:W], sn[:W], concurrency=args.concurrency, group=args.group)
@@ -122,14 +197,15 @@ def main():
     if not args.no_profile and rank == 0:
         # per-kernel breakdown from one extra, untimed group with every launch bracketed
         gp.profile(True); gp.profile_reset()
-        gp.run_batch(W, min(K, args.group), ell[W:W + min(K, args.group)], sn[W:W + min(K, args.group)], concurrency=1, group=args.group)
+        kk = min(K, args.group)
+        gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
         prof_all = gp.profile_get(); gp.profile(False)
-        prof_all_fits = min(K, args.group)
+        prof_all_fits = kk
     m64 = None
-    if rank == 0 and world == 1 and not args.no_profile:
+    if rank == 0 and world == 1 and not args.no_profile and not args.no_extras:
         # "m = 1 (also report m = 64)" -- the same steps with 64 test points riding along each fit (untimed extra)
         rng = np.random.default_rng(7)
-        Xs64 = rng.standard_normal((years, 64, d))
+        Xs64 = rng.standard_normal((len(my_years), 64, d))
         gp.upload_batch(Xb, yb, Xs64, group=args.group, concurrency=args.concurrency)
         k64 = min(K, args.group)
         gp.run_batch(W, k64, ell[W:W + k64], sn[W:W + k64], concurrency=args.concurrency, group=args.group)
@@ -145,20 +221,26 @@ def main():
         elapsed = float(t.item())
     assert np.all(r["info"] == 0) and np.all(np.isfinite(r["mean"]))
 
-    fits = K * world
+    fits = args.steps * G * (world if args.scaling == "weak" else 1)       # whole-job timed fits
     value = fits / elapsed
-    flops_fit = n ** 3 / 3 + n ** 2 / 2 + n / 6 + n * n * d + n * n / 2 + 2 * n * n + m * (2 * n * d + n * n + 4 * n)
+    flops_fit = flops_per_fit(n, d, m)
+    sn_t = sn[W:]
     out = {
         "metric": "GP fits/sec (n x n fp64, kernel+Cholesky+predict)", "value": value, "unit": "fits/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "configs[2]: n=%d d=%d fp64 RBF GPR, batch of retrospective years x hyper-parameter grid, "
-                               "one step = the %d years at one grid point factorised in lockstep, each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1" % (n, d, G),
-                   "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / K, "years_resident": years, "lockstep_group": args.group, "groups_in_flight": args.concurrency, "parallelism": "years sharded over %d GPU(s), no collective" % world},
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "configs[2]: n=%d d=%d fp64 RBF GPR, batch of retrospective years x hyper-parameter grid (%s: %dx%d over l = sqrt(d) logspace(-1,1), sn~ = logspace(-3,1)), "
+                               "one step = the %d years at one grid point factorised in lockstep, each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1"
+                               % (n, d, args.grid, len(grid_axes(d, args.grid)[0]), len(grid_axes(d, args.grid)[1]), G),
+                   "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / max(1, fits // world if args.scaling == "weak" else fits), "years_resident_per_rank": len(my_years),
+                   "lockstep_group": args.group, "groups_in_flight": args.concurrency, "grid": args.grid,
+                   "parallelism": ("years sharded over %d GPU(s): every rank its own %d years, no data-path collective" % (world, years)) if args.scaling == "weak" else
+                                  ("the fixed %d-fit job dealt round-robin over %d GPU(s), no data-path collective" % (fits, world))},
         "whole_fit_tflops": value * flops_fit / 1e12 / world,
         "whole_fit_frac_of_fp64_mfma_peak": value * flops_fit / 1e12 / world / PEAK_F64_MFMA_TFLOPS,
-        # K~ = k(X,X) + sn I with k <= 1: eigenvalues in [sn, n + sn] -> cond(K~) <= (n + sn)/sn over the grid used
-        "cond_upper_bound": {"min": float((n + sn[W:].max()) / sn[W:].max()), "max": float((n + sn[W:].min()) / sn[W:].min())},
+        # K~ = k(X,X) + sn I with k <= 1: eigenvalues in [sn, n + sn] -> cond(K~) <= (n + sn)/sn over the grid points timed
+        "cond_upper_bound": {"min": float((n + sn_t.max()) / sn_t.max()), "max": float((n + sn_t.min()) / sn_t.min())},
+        "kernel_function_parity": "RBF is not in the reference (its kernel is X expm(lM) X^T): the fit/solve/predict skeleton is pinned by the reference's goldens, the RBF function itself only by scikit-learn (tests/test_oracle_golden.py)",
     }
     if m64 is not None:
         out["m64"] = m64
@@ -169,77 +251,163 @@ def main():
             out["roofline"] = {"bound": "mfma", "kernel": "sigp::syrk128_kernel<double,false> (inner + trailing updates C -= P P^T, fp64 v_mfma_f64_16x16x4_f64)",
                                "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS,
                                "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
-                               "flops_per_launch": dom["flops"] / dom["launches"]}
-            # HBM-side traffic of the same kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot
-            # share a pass, and PMC collection serialises kernels), summarised under profiles/ by tools/collect_profiles.sh
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_syrk128.json")))
-                if n == 8192 and d == 8 and args.group == 40 and args.outer == 8:
-                    out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_unit"] = "bytes per launch (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, profiles/r01_pmc_syrk128.json)"
-                    out["roofline"]["algorithmic_c_bytes_per_launch"] = dom["bytes"] / dom["launches"]
-            except Exception:
-                pass
+                               "flops_per_launch": dom["flops"] / dom["launches"],
+                               "flops_note": "algorithmic: 2*128*128*K per off-diagonal tile, the lower half (128*129*K) per diagonal tile"}
+            # HBM-side traffic of the same kernel is NOT measured in this run: it comes from separate rocprofv3 --pmc passes of this
+            # command (FETCH_SIZE / WRITE_SIZE cannot share a pass, and PMC collection serialises kernels), summarised under
+            # profiles/ by tools/collect_profiles.sh + tools/summarize_pmc.py
+            for rnd in ("r02", "r01"):
+                pth = os.path.join(ROOT, "profiles", "%s_pmc_syrk128.json" % rnd)
+                if not os.path.exists(pth):
+                    continue
+                try:
+                    pm = json.load(open(pth))
+                    if n == 8192 and d == 8 and args.group == 40 and args.outer == 8:
+                        out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                        out["roofline"]["traffic_source"] = "from profiles/%s_pmc_syrk128.json (rocprofv3 --pmc passes of this command, NOT this run): bytes per launch = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % rnd
+                        out["roofline"]["algorithmic_c_bytes_per_launch"] = dom["bytes"] / dom["launches"]
+                except Exception:
+                    pass
+                break
         else:
             out["roofline"] = None
-        kb = prof["kbuild"]
         src, nf = (prof_all, prof_all_fits) if prof_all is not None else (prof, K)
         out["kernels"] = {k: {"ms_per_fit": v["ms"] / nf, "launches_per_fit": v["launches"] / nf,
                               "tflops": (v["flops"] / (v["ms"] * 1e-3) / 1e12) if v["ms"] > 0 else None,
                               "GBps": (v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["ms"] > 0 else None} for k, v in src.items()}
         out["kernels_note"] = "per-kernel table from one extra untimed lockstep group with every launch bracketed; roofline from the timed region"
-        del kb
     gp.close()
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["other_configs"] = other_configs(local)
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # reference-idiom CPU path (oracle, call-for-call north/June1st.py:264-277) on the host cores, one fit
-        ncpu = os.cpu_count()
-        cpu_model = "unknown"
-        try:
-            with open("/proc/cpuinfo") as f:
-                cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
-        except OSError:
-            pass
-        import scipy
-        try:
-            from threadpoolctl import threadpool_info
-            ncpu = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [ncpu])
-        except Exception:
-            pass
-        from oracle import gp_oracle as O      # the CPU checker / baseline: imported for this leg only, after the timed region
-        # the sample is the FIRST TIMED STEP of the run above: data set W % years, hyper-parameters of step W
-        nb = n if n <= 8192 else 8192
-        ds0 = W % years
-        if nb == n:
-            Xc, yc, Xsc = Xb[ds0], yb[ds0], Xsb[ds0]
-        else:
-            Xc, yc, Xsc = synthetic_problem(nb, d, 20240002, m=1)
-        ell0, sn0 = float(ell[W]), float(sn[W])
-        t0 = time.perf_counter()
-        ref = O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=True)
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
-                               "sample": "1 fit (the first timed step: year %d, l=%.4g, sn~=%.3g), n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (NumPy %s / SciPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d, CPU: %s)" % (ds0, ell0, sn0, nb, d, np.__version__, scipy.__version__, ncpu, os.cpu_count(), cpu_model),
-                               "seconds": tc}
-        t0 = time.perf_counter()
-        O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=False)
-        tb = time.perf_counter() - t0
-        out["cpu_baseline_best_practice"] = {"value": 1.0 / tb, "unit": "fits/s", "cores": ncpu, "kind": "port", "seconds": tb,
-                                             "sample": "1 fit, same inputs, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)"}
-        if nb == n:   # parity of the timed configuration against the CPU path on the same inputs: the timed lockstep batch's own
-            # result for that step, and the same fit through the single-fit entry point
-            with GPR(kernel="rbf", device=local) as g2:
-                g2.fit(Xc, yc, ell0, sn0, Xs=Xsc)
-                mu, var = g2.predict(Xsc)
-            relf = lambda a, b: float(abs(a - b) / abs(b))
-            out["parity"] = {"batch_step0_mean_rel": relf(r["mean"][0, 0], ref["fmean"][0]), "batch_step0_var_rel": relf(r["var"][0, 0], ref["fvar"][0]),
-                             "batch_step0_nlml_rel": relf(r["nlml"][0], ref["nlml"]),
-                             "single_fit_mean_rel": relf(mu[0], ref["fmean"][0]), "single_fit_var_rel": relf(var[0], ref["fvar"][0]), "tolerance": 1e-08}
-            assert max(out["parity"]["batch_step0_mean_rel"], out["parity"]["batch_step0_var_rel"]) <= 1e-8, out["parity"]
+        cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, len(my_years), r, local)
     if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def timed(fn, reps, warm=1):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts
+
+
+def other_configs(local):
+    """The other BASELINE configurations on ONE GPU (untimed extras, not the metric): latency of a single fit at
+    configs[1] / [3] / [4] shape with its roofline fraction, the MLII (nlML + exact gradient) evaluation, and the
+    reference's own kernel at the reference's own size batched over the 20x20 grid."""
+    import torch
+    from seaiceextentforecasting_amd import GPR
+    rec = {}
+
+    def single(tag, kernel, dtype, n, d, ell, sn, seed, reps, peak):
+        X, y, Xs = synthetic_problem(n, d, seed, m=1)
+        with GPR(kernel=kernel, dtype=dtype, device=local) as g:
+            g.fit(X, y, ell, sn, Xs=Xs)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(reps):
+                g.refit(ell, sn)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            e = {"ms_per_fit": 1e3 * dt, "fits_per_s": 1.0 / dt, "tflops": flops_per_fit(n, d) / dt / 1e12,
+                 "frac_of_peak": flops_per_fit(n, d) / dt / 1e12 / peak, "peak_tflops": peak, "note": "one fit at a time (latency), GPR.refit on resident data"}
+            if dtype == "f32":
+                e["refinement_residual"] = g.refine_residual_
+        rec[tag] = e
+        return X, y
+
+    single("configs[1] n=4096 d=8 fp64 RBF single fit", "rbf", "f64", 4096, 8, np.sqrt(8.0), 1e-2, 20240001, 5, PEAK_F64_MFMA_TFLOPS)
+    single("configs[3] n=16384 d=16 fp64 RBF single fit on one GPU", "rbf", "f64", 16384, 16, 4.0, 1e-2, 20240003, 2, PEAK_F64_MFMA_TFLOPS)
+    single("configs[4] n=32768 d=32 fp32 Matern-5/2 + fp64 refinement on one GPU", "matern52", "f32", 32768, 32, np.sqrt(32.0), 1e-1, 20240004, 2, PEAK_F32_MFMA_TFLOPS)
+    # MLII: nlML + exact gradient (north/June1st.py:235-257 with the true derivative), the O(n^3) hot spot of an optimiser run
+    ml = {}
+    for n in (4096, 8192):
+        X, y, _ = synthetic_problem(n, 8, 20240001, m=1)
+        th = np.log([np.sqrt(8.0), 1e-2])
+        with GPR(kernel="rbf", device=local) as g:
+            g.set_data(X, y)
+            g.nlml(th, grad="exact")
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                g.nlml(th, grad="exact")
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+            fl = mlii_flops(n, 8)
+            ml["n=%d" % n] = {"ms": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                              "algorithmic_flops": fl}
+    ml["note"] = "one MLII evaluation = fit (n^3/3) + L~^-T by recursive triangular inversion (n^3/3) + lower K~^-1 = U U^T (n^3/3) + O(n^2 d) derivative/reductions"
+    rec["mlii"] = ml
+    return rec
+
+
+def mlii_flops(n, d):
+    return flops_per_fit(n, d, 0) + 2 * n ** 3 / 3 + n * n * (3 * d + 30)
+
+
+def cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, nsets, r, local):
+    """The reference-idiom CPU path (oracle, call-for-call north/June1st.py:264-277) on the host cores, on a bounded sample:
+    BASELINE.md section 2 protocol (1 warm-up + 3 timed, median) at n = 64 and 4096; at n = 8192 --cpu-reps timed fits
+    (default 1: a reference-idiom fit takes ~48 s there) of the FIRST TIMED STEP's inputs."""
+    from seaiceextentforecasting_amd import GPR
+    n, d = args.n, args.d
+    ncpu = os.cpu_count()
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    import scipy
+    try:
+        from threadpoolctl import threadpool_info
+        ncpu = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [ncpu])
+    except Exception:
+        pass
+    from oracle import gp_oracle as O      # the CPU checker / baseline: imported for this leg only, after the timed region
+    env = "NumPy %s / SciPy %s / OpenBLAS, %d BLAS threads, os.cpu_count()=%d, CPU: %s" % (np.__version__, scipy.__version__, ncpu, os.cpu_count(), cpu_model)
+    proto = {}
+    for nn, dd, seed in ((64, 4, 20240000), (4096, 8, 20240001)):
+        Xc, yc, Xsc = synthetic_problem(nn, dd, seed, m=1)
+        e0, s0 = float(np.sqrt(dd)), 1e-2
+        med_ref, _ = timed(lambda: O.fit_predict(Xc, yc, Xsc, e0, s0, kind="rbf", ref_idiom=True), 3)
+        med_best, _ = timed(lambda: O.fit_predict(Xc, yc, Xsc, e0, s0, kind="rbf", ref_idiom=False), 3)
+        proto["n=%d d=%d" % (nn, dd)] = {"reference_idiom_fits_per_s": 1.0 / med_ref, "reference_idiom_s": med_ref,
+                                         "best_practice_fits_per_s": 1.0 / med_best, "best_practice_s": med_best, "protocol": "1 warm-up + 3 timed, median"}
+    # n = 8192: the sample is the FIRST TIMED STEP of the run above (its first member: data set W % nsets, hyper-parameters of fit W)
+    nb = n if n <= 8192 else 8192
+    ds0 = W % nsets
+    if nb == n:
+        Xc, yc, Xsc = Xb[ds0], yb[ds0], Xsb[ds0]
+    else:
+        Xc, yc, Xsc = synthetic_problem(nb, d, 20240002, m=1)
+    ell0, sn0 = float(ell[W]), float(sn[W])
+    reps = max(1, args.cpu_reps)
+    ref = {}
+    def run_ref():
+        ref["r"] = O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=True)
+    tc, ts = timed(run_ref, reps, warm=1 if reps > 1 else 0)
+    ref = ref["r"]
+    out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "fits/s", "cores": ncpu, "kind": "port",
+                           "sample": "%d timed fit(s)%s (the first timed step: data set %d, l=%.4g, sn~=%.3g), n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (%s)"
+                                     % (reps, " after 1 warm-up, median" if reps > 1 else ", cold", ds0, ell0, sn0, nb, d, env),
+                           "seconds": tc, "protocol_other_sizes": proto}
+    tb, _ = timed(lambda: O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=False), reps, warm=1 if reps > 1 else 0)
+    out["cpu_baseline_best_practice"] = {"value": 1.0 / tb, "unit": "fits/s", "cores": ncpu, "kind": "port", "seconds": tb,
+                                         "sample": "same inputs and repetitions, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)"}
+    if nb == n:   # parity of the timed configuration against the CPU path on the same inputs: the timed lockstep batch's own
+        # result for that step, and the same fit through the single-fit entry point
+        with GPR(kernel="rbf", device=local) as g2:
+            g2.fit(Xc, yc, ell0, sn0, Xs=Xsc)
+            mu, var = g2.predict(Xsc)
+        relf = lambda a, b: float(abs(a - b) / abs(b))
+        out["parity"] = {"batch_step0_mean_rel": relf(r["mean"][0, 0], ref["fmean"][0]), "batch_step0_var_rel": relf(r["var"][0, 0], ref["fvar"][0]),
+                         "batch_step0_nlml_rel": relf(r["nlml"][0], ref["nlml"]),
+                         "single_fit_mean_rel": relf(mu[0], ref["fmean"][0]), "single_fit_var_rel": relf(var[0], ref["fvar"][0]), "tolerance": 1e-08}
+        assert max(out["parity"]["batch_step0_mean_rel"], out["parity"]["batch_step0_var_rel"]) <= 1e-8, out["parity"]
 
 
 if __name__ == "__main__":

@@ -40,7 +40,7 @@ enum { SIGP_MAT_K = 0, SIGP_MAT_L = 1 };
  * kbuild_kernel(+ride_build), potrf_diag_kernel, gemm_mfma_kernel<32,128> (panel solve),
  * gemm_mfma_kernel<64,64> (updates with few tiles), syrk128_kernel (inner + trailing updates), epilogue_kernel */
 enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_SMALL = 3,
-       SIGP_KC_SYRK128 = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_COUNT = 6 };
+       SIGP_KC_SYRK128 = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_SMALL = 6 /* smallgp_kernel */, SIGP_KC_COUNT = 7 };
 
 #define SIGP_MAX_RIDE 127 /* test points that can ride along one factorisation */
 
@@ -105,6 +105,28 @@ int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t st
 int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency);
 int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* ell,
                    const double* sn_tilde, int concurrency, double* out, double* mean, double* var);
+
+/* The reference's OWN kernel at the reference's OWN size, batched: the retro loop
+ * (north/retrospective_forecasts/September1st_retro.py:176-248: 3 regions x ~40 years of independent fits, n = year - 1979 <= 45)
+ * times the 20 x 20 (l, sn~) grid of north/June1st.py:210-211 -- ONE WORKGROUP PER FIT, everything in LDS, one launch for the lot.
+ * Each fit is north/June1st.py:264-277 + :246: K~ = X expm(l M) X^T + sn~ I, Cholesky, A~, sigma_f, k*, k**, fmean, fvar, nlML.
+ * Data sets are ragged (n, N, m per set, 1 <= n <= 128, 0 <= m <= 8) and staged once in factored form (one
+ * eigendecomposition per data set serves every l of the grid):
+ *   A   [(n+m)][N] = [X ; Xs] Q      lam [N] = eigenvalues of M = Q diag(lam) Q^T        (lam_mode 0: weights exp(l lam_k))
+ *   A   [(n+m)][N] = [X ; Xs] U      lam [N] = eigenvalues of a host-side Sigma~ = U diag(lam) U^T   (lam_mode 1: weights lam_k;
+ *                                    this is how scipy's Pade expm(l M) -- the reference's own numbers at l = 3.1e10 -- goes through)
+ * so that K~ = A_train diag(w) A_train^T + sn~ I.  Pools are flat double arrays; *_off give each set's start (in doubles).
+ * sigp_small_run: fit i uses data set set_index[i] with (ell[i], sn_tilde[i]); out [nprob][4] = sigma_f, nlML, info, sigma_n
+ * (info > 0: LAPACK pivot index, other entries +inf, mean/var NaN -- north/June1st.py:254-256); mean / var [nprob][mstride]. */
+int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int64_t* N, const int64_t* m, const int32_t* lam_mode,
+                      const double* A_pool, const int64_t* A_off, const double* y_pool, const int64_t* y_off,
+                      const double* lam_pool, const int64_t* lam_off);
+int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde,
+                   double* out, double* mean, double* var, int64_t mstride);
+
+/* named scalars of the last operation: "refine_residual" (fp32 engine: max|y - K~ alpha~| / max|y| after the last refinement
+ * step), "matrix_bytes" (device bytes held by this handle's matrix / factor buffers). */
+int sigp_get_stat(sigp_handle* h, const char* name, double* value);
 
 /* K7 (explicit): alpha~ = K~^-1 y  [n]  (north/June1st.py:266; alpha of :271 is alpha~/sigma_f). */
 int sigp_get_alpha(sigp_handle* h, double* alpha_tilde);

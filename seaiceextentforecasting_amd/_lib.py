@@ -11,11 +11,13 @@ LIB_PATH = os.path.join(_HERE, "libsigp.so")
 
 OK, NOT_SPD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
 KERNEL_IDS = {"netdiffusion": 0, "rbf": 1, "matern52": 2}
-KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_small": 3, "syrk128": 4, "epilogue": 5}
+KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_small": 3, "syrk128": 4, "epilogue": 5, "small": 6}
 MAX_RIDE = 127
 
 _dp = C.POINTER(C.c_double)
 _i64 = C.c_int64
+_ip64 = C.POINTER(C.c_int64)
+_ip32 = C.POINTER(C.c_int32)
 _h = C.c_void_p
 
 # every symbol include/sigp.h declares: name -> (restype, argtypes)
@@ -38,6 +40,9 @@ SIGNATURES = {
     "sigp_batch_upload": (C.c_int, [_h, _i64, _dp, _i64, _dp, _i64, _dp, _i64, _i64, _i64, _i64]),
     "sigp_batch_reserve": (C.c_int, [_h, _i64, C.c_int]),
     "sigp_batch_run": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
+    "sigp_small_upload": (C.c_int, [_h, _i64, _ip64, _ip64, _ip64, _ip32, _dp, _ip64, _dp, _ip64, _dp, _ip64]),
+    "sigp_small_run": (C.c_int, [_h, _i64, _ip64, _dp, _dp, _dp, _dp, _dp, _i64]),
+    "sigp_get_stat": (C.c_int, [_h, C.c_char_p, _dp]),
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
     "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, C.POINTER(C.c_double), _dp]),
@@ -58,32 +63,47 @@ SIGNATURES = {
 }
 
 _lib = None
+_dbg = None
+DEBUG_LIB_PATH = os.path.join(_HERE, "libsigp_debug.so")
 
 
 class SigpError(RuntimeError):
     pass
 
 
-def load():
-    """dlopen libsigp.so and bind every declared symbol.  Fails loudly when the HIP build is missing."""
-    global _lib
-    if _lib is not None:
+def load(debug=False):
+    """dlopen libsigp.so and bind every declared symbol.  Fails loudly when the HIP build is missing.
+    ``debug=True`` (tools/ only) loads libsigp_debug.so instead: the same library plus the micro-benchmark entry
+    points of include/sigp_debug.h; the product package never asks for it."""
+    global _lib, _dbg
+    if debug and _dbg is not None:
+        return _dbg
+    if not debug and _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise SigpError("libsigp.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                        "or `make -C seaiceextentforecasting_amd/csrc` (there is no CPU fallback)" % LIB_PATH)
+    path = DEBUG_LIB_PATH if debug else LIB_PATH
+    if not os.path.exists(path):
+        raise SigpError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "or `make -C seaiceextentforecasting_amd/csrc%s` (there is no CPU fallback)" % (path, " debug" if debug else ""))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # must precede HIP runtime initialisation to take effect
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
+    if debug:
+        _dbg = lib
+    else:
+        _lib = lib
     return lib
 
 
 def ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
+
+
+def iptr(a):
+    """pointer to an int64 / int32 NumPy array"""
+    return a.ctypes.data_as(_ip64 if a.dtype == np.int64 else _ip32)
 
 
 def f64(a, ndim=None):

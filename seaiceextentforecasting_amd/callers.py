@@ -42,20 +42,25 @@ def detrend(dataset, fmin=None, fmax=None):
     return dataset
 
 
+def _mse_skill(obs, forecast):
+    """1 - MSE(forecast) / MSE(climatology), climatology = the mean of the observations."""
+    obs = np.asarray(obs, dtype=np.float64)
+    err = np.mean((obs - forecast) ** 2)
+    clim = np.mean((obs - np.nanmean(obs)) ** 2)
+    return (1 - (err / clim)).round(3)
+
+
 def skill(GPR, SIEs, SIEs_dt, fmin, fmax, regions):
-    """MSE skill scores ``1 - MSE/MSE_clim`` of the retrended and detrended forecasts, rounded to 3 decimals
-    (north/retrospective_forecasts/June1st_retro.py:293-314).  Returns (skill_rt, skill_dt, dt_obs)."""
+    """MSE skill scores of the retrended and detrended forecasts, rounded to 3 decimals (behaviour of
+    north/retrospective_forecasts/June1st_retro.py:293-314).  The detrended observation of forecast year t is the
+    entry of year t in the series detrended with cut-off t.  Returns (skill_rt, skill_dt, dt_obs)."""
+    years = np.arange(fmin, fmax + 1)
     skill_rt, skill_dt, dt_obs = [], [], []
     for region in regions:
-        dt = [SIEs_dt[region][t - (fmin - 1), t - 1979] for t in range(fmin, fmax + 1)]
+        dt = list(np.asarray(SIEs_dt[region])[years - (fmin - 1), years - 1979])
         dt_obs.append(dt)
-        obs_rt = np.asarray(SIEs[region])[fmin - 1979:]
-        a = np.mean((obs_rt - GPR[region + "_fmean_rt"]) ** 2)
-        b = np.mean((obs_rt - np.nanmean(obs_rt)) ** 2)
-        skill_rt.append((1 - (a / b)).round(3))
-        c = np.mean((np.asarray(dt) - GPR[region + "_fmean"]) ** 2)
-        d = np.mean((np.asarray(dt) - np.nanmean(dt)) ** 2)
-        skill_dt.append((1 - (c / d)).round(3))
+        skill_rt.append(_mse_skill(np.asarray(SIEs[region])[fmin - 1979:], GPR[region + "_fmean_rt"]))
+        skill_dt.append(_mse_skill(dt, GPR[region + "_fmean"]))
     return skill_rt, skill_dt, dt_obs
 
 

@@ -50,6 +50,14 @@ template <> struct Num<float> {
 
 constexpr int KT = Num<double>::KT;   // (fp64 names kept for the fp64-only call sites)
 
+// Timing-ablation switches (GemmArgsT::dbg / ::stamp, kbuild flags 2|4, potrf_diag skip bits) exist for tools/*_bench.py only:
+// they are live in libsigp_debug.so (-DSIGP_DEBUG_TOOLS) and compile out of the product library.
+#ifdef SIGP_DEBUG_TOOLS
+constexpr int DBG_MASK = ~0;
+#else
+constexpr int DBG_MASK = 0;
+#endif
+
 enum { GEMM_SUB = 0, GEMM_SET = 1, GEMM_SETNEG = 2 };   // C -= A B^T | C = A B^T | C = -A B^T
 
 template <typename T>
@@ -220,12 +228,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   }
 
   const int nst = g.K / KTe;
+  const int dbg = g.dbg & DBG_MASK;
   SIGP_GLOAD(0);
   SIGP_SSTORE(0);
   __syncthreads();
   for (int s = 0; s < nst; ++s) {
     const int buf = s & 1;
-    if (s + 1 < nst && !(g.dbg & 1)) SIGP_GLOAD((s + 1) * KTe);
+    if (s + 1 < nst && !(dbg & 1)) SIGP_GLOAD((s + 1) * KTe);
     const T* Ab = As + (buf * TM + wm * WTM + lr) * LDPe + lq;
     const T* Bb = BT ? Bs + (buf * KTe + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDPe + lq;
 #pragma unroll
@@ -240,8 +249,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = N_::mfma(a[i], b[j], acc[i][j]);
     }
-    if (s + 1 < nst && !(g.dbg & 2)) SIGP_SSTORE(buf ^ 1);
-    if (!(g.dbg & 4)) __syncthreads();
+    if (s + 1 < nst && !(dbg & 2)) SIGP_SSTORE(buf ^ 1);
+    if (!(dbg & 4)) __syncthreads();
   }
 #undef SIGP_GLOAD
 #undef SIGP_SSTORE

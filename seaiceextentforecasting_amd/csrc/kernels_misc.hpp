@@ -44,7 +44,8 @@ struct alignas(4 * sizeof(TO)) KbOut4 { TO v[4]; };
 template <typename TO>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
-                                                     const KParams* __restrict__ kps, int flags) {
+                                                     const KParams* __restrict__ kps, int flags_in) {
+  const int flags = flags_in & (DBG_MASK | 1);
   const int full = flags & 1;      // flag bits 2 / 4: timing ablations (no covariance function / no store)
   int bi, bj;                      // 64-row tile, 128-column tile
   if (full) {

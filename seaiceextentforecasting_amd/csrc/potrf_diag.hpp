@@ -47,8 +47,9 @@ __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * B
 // blockIdx.x = batch member: A += b*strideA, Linv += b*strideL, info += b.
 template <typename T>
 __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv,
-                                                                  int* __restrict__ info, int pivot_base, int skip, long strideA,
+                                                                  int* __restrict__ info, int pivot_base, int skip_in, long strideA,
                                                                   long strideL) {
+  const int skip = skip_in & (DBG_MASK | 32);   // bits 1..16: phase ablations of tools/diag_bench.py (debug library only)
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v2_t v2_t;

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <functional>
 #include <limits>
+#include <mutex>
 #include <chrono>
 #include <string>
 #include <type_traits>
@@ -18,6 +19,7 @@
 #include "gemm_mfma.hpp"
 #include "kernels_misc.hpp"
 #include "potrf_diag.hpp"
+#include "smallgp.hpp"
 #include "syrk128.hpp"
 
 using namespace sigp;
@@ -69,6 +71,8 @@ struct sigp_handle {
   double* gK = nullptr; long cap_gK = 0;
   double* gD = nullptr; long cap_gD = 0;
   double* gPart = nullptr; long cap_gPart = 0;
+  double* gSig = nullptr; long cap_gSig = 0;  // MLII gradient (reference kernel): M Sigma~ padded [dp][dp] and X (M Sigma~) [n_pad][dp] --
+  double* gT = nullptr; long cap_gT = 0;      // separate from Sig / T, which sigp_predict reads after a fit
   // fp32 engine (dtype == SIGP_F32): fp32 factor + fp64 iterative refinement (BASELINE configs[4])
   float* fmat = nullptr; float* fdinv = nullptr; float* fZ = nullptr; long cap_f_npad = 0;
   double* xq = nullptr;      // [4][n_pad] refined solutions: row 0 alpha~ = K~^-1 y, rows 1..m  w_j = K~^-1 k~*_j
@@ -83,6 +87,15 @@ struct sigp_handle {
   // batch data (device resident)
   double* bX = nullptr; double* by = nullptr; double* bXs = nullptr;
   long b_count = 0, b_n = 0, b_d = 0, b_dp = 0, b_m = 0, b_npad = 0;
+  // small-order batches of the reference kernel (one workgroup per fit): resident data sets + per-call problem list
+  std::vector<SmallSet> sm_sets;              // host copy (validation, LDS sizing)
+  SmallSet* sm_sets_dev = nullptr;
+  double* sm_A = nullptr; long cap_sm_A = 0;
+  double* sm_y = nullptr; long cap_sm_y = 0;
+  double* sm_lam = nullptr; long cap_sm_lam = 0;
+  SmallProb* sm_probs = nullptr; long cap_sm_probs = 0;
+  double* sm_out = nullptr; long cap_sm_out = 0;   // [nprob][4 + 2*mstride]
+  int sm_ch = 32, sm_mmax = 0; long sm_lds = 0;
   // state
   int kernel_id = -1;
   double ell = 0, sn_tilde = 0;
@@ -270,9 +283,18 @@ void prof_drain(sigp_handle* h) {
 
 // hipFuncSetAttribute is per device: remember per (kernel instantiation, device) whether the dynamic-LDS limit was raised
 constexpr int MAX_DEVICES = 64;
+// (distinct handles may be driven from distinct threads: the flag is only set after the attribute call returned, and
+// both happen under the mutex, so no thread can launch with > 64 KB of dynamic LDS before the limit is raised)
 struct AttrOnce {
+  std::mutex mu;
   bool done[MAX_DEVICES] = {false};
-  bool need(int dev) { if (dev < 0 || dev >= MAX_DEVICES) return true; if (done[dev]) return false; done[dev] = true; return true; }
+  hipError_t set(int dev, const void* fn, int lds_bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev >= 0 && dev < MAX_DEVICES && done[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e == hipSuccess && dev >= 0 && dev < MAX_DEVICES) done[dev] = true;
+    return e;
+  }
 };
 
 // ---- GEMM launch ----------------------------------------------------------------------------------
@@ -283,7 +305,7 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   auto kern = gemm_mfma_kernel<T, TM, TN, WM, WN, MODE, BT>;
   constexpr int lds = gemm_lds_bytes<T, TM, TN, BT>();
   static AttrOnce attr;
-  if (attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  HIPCHK(h, attr.set(h->device, (const void*)kern, lds));
   hipLaunchKernelGGL(kern, dim3(nt, std::max(1, g.batch)), dim3(256), lds, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -297,7 +319,7 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
   static AttrOnce attr;
-  if (attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)syrk128_kernel<T, SET>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+  HIPCHK(h, attr.set(h->device, (const void*)syrk128_kernel<T, SET>, SY_LDS_BYTES));
   hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -311,7 +333,11 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   const double nt1 = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
   const int nt = (int)nt1 * nb;
   if (nt <= 0) return SIGP_OK;
-  const double flops = nt1 * nb * 2.0 * NB * NB * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
+  // algorithmic work: a diagonal tile of a lower (SYRK-shaped) update only needs its lower half; the kernel computes the
+  // whole tile, but the strictly-upper NB(NB-1)/2 entries are not counted as flops
+  int ndiag = 0;
+  if (g.lower) for (int c = g.c0; c < g.c1; ++c) ndiag += (c >= g.r0 && c < g.r1);
+  const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1)) * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
     if (h->opt_c_dma) g.dbg |= 128;
@@ -374,7 +400,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   }
   HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
   static AttrOnce diag_attr;
-  if (diag_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, diag_lds));
+  HIPCHK(h, diag_attr.set(h->device, (const void*)potrf_diag_kernel<Real>, diag_lds));
   const bool la = h->opt_lookahead != 0;
   hipStream_t sp = la ? s.s_pan : s.s_upd;   // panel stream
   hipStream_t su = s.s_upd;
@@ -468,7 +494,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     {
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (double)below * 2.0 * NB * NB * NB * (Wp * (Wp + 1) / 2), nb * (double)below * 2.0 * Wp * NB * NB * 8);
       static AttrOnce strip_attr;
-      if (strip_attr.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)panel_strip_kernel<Real>, hipFuncAttributeMaxDynamicSharedMemorySize, SY_LDS_BYTES));
+      HIPCHK(h, strip_attr.set(h->device, (const void*)panel_strip_kernel<Real>, SY_LDS_BYTES));
       StripArgsT<Real> a{M, ld, matStride, mt, MT_LD, mtStride, J0 + Wp, J0, Wp};
       hipLaunchKernelGGL(panel_strip_kernel<Real>, dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
       HIPCHK(h, hipGetLastError());
@@ -859,7 +885,9 @@ int sigp_destroy(sigp_handle* h) {
   (void)hipDeviceSynchronize();
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
-  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->xq, h->rq, h->fpart};
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
+  if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
+  if (h->sm_probs) (void)hipFree(h->sm_probs);
   if (h->fmat) (void)hipFree(h->fmat);
   if (h->fdinv) (void)hipFree(h->fdinv);
   if (h->fZ) (void)hipFree(h->fZ);
@@ -892,7 +920,10 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
-  if (!strcmp(name, "c_dma")) { h->opt_c_dma = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "c_dma")) {
+    if (!DBG_MASK) return fail(h, SIGP_BAD_ARG, "c_dma is a measurement switch of libsigp_debug.so");
+    h->opt_c_dma = value != 0; return SIGP_OK;
+  }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
@@ -1452,24 +1483,25 @@ int sigp_fit_batch(sigp_handle* h, int64_t batch, int kernel_id, const double* X
   return sigp_batch_run(h, 0, batch, kernel_id, ell, sn_tilde, concurrency, out, mean, var);
 }
 
-// D <- X S X^T for a symmetric S [N][N] on the host (full symmetric result, zero on the padding)
+// D <- X S X^T for a symmetric S [N][N] on the host (full symmetric result, zero on the padding).  Uses its own
+// workspaces (gSig, gT): the fitted state (Sig, T) that sigp_predict reads stays intact.
 static int build_xsxt(sigp_handle* h, const double* S, int64_t lds, double* D) {
   hipStream_t st = h->slots[0].s_upd;
   const long N = h->d, dp = h->dp, n_pad = h->n_pad, ld = n_pad;
   int rc;
-  if ((rc = ensure(h, &h->Sig, &h->cap_Sig, dp * dp))) return rc;
-  if ((rc = ensure(h, &h->T, &h->cap_T, n_pad * dp))) return rc;
+  if ((rc = ensure(h, &h->gSig, &h->cap_gSig, dp * dp))) return rc;
+  if ((rc = ensure(h, &h->gT, &h->cap_gT, n_pad * dp))) return rc;
   if ((rc = ensure(h, &h->stage, &h->cap_stage, N * lds))) return rc;
   HIPCHK(h, hipMemcpyAsync(h->stage, S, (size_t)((N - 1) * lds + N) * sizeof(double), hipMemcpyHostToDevice, st));
   const long tot = dp * dp;
-  hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)lds, (int)N, (int)N, h->Sig, (int)dp, (int)dp);
+  hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)lds, (int)N, (int)N, h->gSig, (int)dp, (int)dp);
   HIPCHK(h, hipGetLastError());
   GemmArgs g{};
-  g.A = h->X; g.lda = dp; g.B = h->Sig; g.ldb = dp; g.C = h->T; g.ldc = dp; g.K = (int)dp;
+  g.A = h->X; g.lda = dp; g.B = h->gSig; g.ldb = dp; g.C = h->gT; g.ldc = dp; g.K = (int)dp;
   g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(dp / 64); g.lower = 0;
   if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
   GemmArgs g2{};
-  g2.A = h->T; g2.lda = dp; g2.B = h->X; g2.ldb = dp; g2.C = D; g2.ldc = ld; g2.K = (int)dp;
+  g2.A = h->gT; g2.lda = dp; g2.B = h->X; g2.ldb = dp; g2.C = D; g2.ldc = ld; g2.K = (int)dp;
   g2.r0 = 0; g2.r1 = (int)(n_pad / 64); g2.c0 = 0; g2.c1 = (int)(n_pad / 64); g2.lower = 0;
   return launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g2);
 }
@@ -1555,6 +1587,98 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   return SIGP_OK;
 }
 
+// ---- the reference's own kernel at the reference's own size: one workgroup per fit (smallgp.hpp) ---------------------
+int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int64_t* N, const int64_t* m, const int32_t* lam_mode,
+                      const double* A_pool, const int64_t* A_off, const double* y_pool, const int64_t* y_off, const double* lam_pool,
+                      const int64_t* lam_off) {
+  if (!h || nsets < 1 || !n || !N || !m || !lam_mode || !A_pool || !A_off || !y_pool || !y_off || !lam_pool || !lam_off)
+    return fail(h, SIGP_BAD_ARG, "small_upload: bad argument");
+  if (h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "small_upload: fp64 engine only");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<SmallSet> sets((size_t)nsets);
+  long totA = 0, toty = 0, totl = 0;
+  int nmax = 0, mmax = 0;
+  for (int64_t i = 0; i < nsets; ++i) {
+    if (n[i] < 1 || n[i] > SM_NMAX) return fail(h, SIGP_BAD_ARG, "small_upload: data set %ld has n = %ld; this path takes 1 <= n <= %d (larger fits go through sigp_fit_predict)", (long)i, (long)n[i], SM_NMAX);
+    if (N[i] < 1 || m[i] < 0 || m[i] > SM_MMAX) return fail(h, SIGP_BAD_ARG, "small_upload: data set %ld: N >= 1 and 0 <= m <= %d required", (long)i, SM_MMAX);
+    if (lam_mode[i] != 0 && lam_mode[i] != 1) return fail(h, SIGP_BAD_ARG, "small_upload: lam_mode must be 0 (exp(l lam)) or 1 (weights)");
+    if (A_off[i] < 0 || y_off[i] < 0 || lam_off[i] < 0) return fail(h, SIGP_BAD_ARG, "small_upload: negative offset");
+    SmallSet& s = sets[(size_t)i];
+    s.a_off = A_off[i]; s.y_off = y_off[i]; s.lam_off = lam_off[i];
+    s.n = (int)n[i]; s.N = (int)N[i]; s.m = (int)m[i]; s.lam_mode = lam_mode[i];
+    totA = std::max<long>(totA, A_off[i] + (n[i] + m[i]) * N[i]);
+    toty = std::max<long>(toty, y_off[i] + n[i]);
+    totl = std::max<long>(totl, lam_off[i] + N[i]);
+    nmax = std::max(nmax, s.n); mmax = std::max(mmax, s.m);
+  }
+  // feature chunk: the largest of 32 / 16 / 8 whose LDS image fits beside the bordered matrix of the largest data set
+  constexpr long LDS_MAX = 160 * 1024 - 64;
+  int ch = 32;
+  while (ch > 8 && smallgp_lds_bytes(nmax, mmax, ch) > LDS_MAX) ch /= 2;
+  if (smallgp_lds_bytes(nmax, mmax, ch) > LDS_MAX) return fail(h, SIGP_BAD_ARG, "small_upload: n = %d with m = %d does not fit in LDS", nmax, mmax);
+  int rc;
+  if ((rc = ensure(h, &h->sm_A, &h->cap_sm_A, totA))) return rc;
+  if ((rc = ensure(h, &h->sm_y, &h->cap_sm_y, toty))) return rc;
+  if ((rc = ensure(h, &h->sm_lam, &h->cap_sm_lam, totl))) return rc;
+  if (h->sm_sets_dev) { HIPCHK(h, hipFree(h->sm_sets_dev)); h->sm_sets_dev = nullptr; }
+  HIPCHK(h, hipMalloc((void**)&h->sm_sets_dev, sets.size() * sizeof(SmallSet)));
+  HIPCHK(h, hipMemcpy(h->sm_sets_dev, sets.data(), sets.size() * sizeof(SmallSet), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->sm_A, A_pool, (size_t)totA * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->sm_y, y_pool, (size_t)toty * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(h, hipMemcpy(h->sm_lam, lam_pool, (size_t)totl * sizeof(double), hipMemcpyHostToDevice));
+  h->sm_sets.swap(sets);
+  h->sm_ch = ch; h->sm_mmax = mmax; h->sm_lds = smallgp_lds_bytes(nmax, mmax, ch);
+  return SIGP_OK;
+}
+
+int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde, double* out,
+                   double* mean, double* var, int64_t mstride) {
+  if (!h || h->sm_sets.empty()) return fail(h, SIGP_BAD_ARG, "small_run: call sigp_small_upload first");
+  if (nprob < 1 || !set_index || !ell || !sn_tilde || !out) return fail(h, SIGP_BAD_ARG, "small_run: bad argument");
+  if (h->sm_mmax > 0 && (!mean || !var || mstride < h->sm_mmax)) return fail(h, SIGP_BAD_ARG, "small_run: mean / var [nprob][mstride >= %d] required", h->sm_mmax);
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<SmallProb> probs((size_t)nprob);
+  for (int64_t i = 0; i < nprob; ++i) {
+    if (set_index[i] < 0 || set_index[i] >= (int64_t)h->sm_sets.size()) return fail(h, SIGP_BAD_ARG, "small_run: fit %ld names data set %ld of %zu", (long)i, (long)set_index[i], h->sm_sets.size());
+    if (!(sn_tilde[i] >= 0) || !std::isfinite(ell[i])) return fail(h, SIGP_BAD_ARG, "small_run: finite ell and sn_tilde >= 0 required");
+    probs[(size_t)i] = SmallProb{(int)set_index[i], 0, ell[i], sn_tilde[i]};
+  }
+  const long ms = std::max<int64_t>(mstride, 1);
+  const long per = 4 + 2 * ms;
+  if (h->cap_sm_probs < nprob) {
+    if (h->sm_probs) HIPCHK(h, hipFree(h->sm_probs));
+    h->sm_probs = nullptr; h->cap_sm_probs = 0;
+    HIPCHK(h, hipMalloc((void**)&h->sm_probs, (size_t)nprob * sizeof(SmallProb)));
+    h->cap_sm_probs = nprob;
+  }
+  int rc;
+  if ((rc = ensure(h, &h->sm_out, &h->cap_sm_out, nprob * per))) return rc;
+  hipStream_t st = h->slots[0].s_upd;
+  HIPCHK(h, hipMemcpyAsync(h->sm_probs, probs.data(), probs.size() * sizeof(SmallProb), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemsetAsync(h->sm_out, 0xff, (size_t)(nprob * per) * sizeof(double), st));   // NaN wherever a set has fewer test points than mstride
+  static AttrOnce attr;
+  HIPCHK(h, attr.set(h->device, (const void*)smallgp_kernel, 160 * 1024 - 64));
+  double* d_out = h->sm_out;
+  double* d_mean = h->sm_out + nprob * 4;
+  double* d_var = d_mean + nprob * ms;
+  {
+    double fl = 0;
+    for (const auto& pb : probs) { const SmallSet& s = h->sm_sets[(size_t)pb.set]; fl += (double)s.n * s.n * s.N + (double)s.n * s.n * s.n / 3 + 2.0 * s.n * s.n * (1 + s.m); }
+    ProfScope ps(h, st, SIGP_KC_SMALL, fl, 0.0);
+    hipLaunchKernelGGL(smallgp_kernel, dim3((unsigned)nprob), dim3(256), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
+                       h->sm_ch, d_out, d_mean, d_var, (int)ms);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)nprob * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (h->sm_mmax > 0) {
+    // device rows have pitch ms; the caller's have pitch mstride (== ms whenever mstride >= 1)
+    HIPCHK(h, hipMemcpyAsync(mean, d_mean, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(var, d_var, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(h, hipStreamSynchronize(st));
+  return SIGP_OK;
+}
+
 // ---- one large fit sharded over GPUs: panel-level entry points (host side: dist.DistributedGPR) ------------
 int64_t sigp_num_blocks(sigp_handle* h) { return h ? h->n_pad / NB : 0; }
 
@@ -1564,9 +1688,9 @@ int sigp_dist_begin(sigp_handle* h) {
   Slot& s = h->slots[0];
   static AttrOnce diag_attr64, diag_attr32;
   if (h->dtype == SIGP_F64) {
-    if (diag_attr64.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(h, diag_attr64.set(h->device, (const void*)potrf_diag_kernel<double>, DIAG_LDS_BYTES));
   } else {
-    if (diag_attr32.need(h->device)) HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+    HIPCHK(h, diag_attr32.set(h->device, (const void*)potrf_diag_kernel<float>, DIAG_LDS_BYTES));
   }
   HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
   return sync_slot(h, s);
@@ -1695,6 +1819,19 @@ int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, do
   return SIGP_OK;
 }
 
+int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
+  if (!h || !name || !value) return SIGP_BAD_ARG;
+  if (!strcmp(name, "refine_residual")) { *value = h->refine_resid; return SIGP_OK; }
+  if (!strcmp(name, "matrix_bytes")) {
+    double b = 0;
+    for (const auto& s : h->slots) if (s.mat) b += (double)s.capB * (double)(s.cap_npad + RIDE) * (double)s.cap_npad * sizeof(double);
+    if (h->fmat) b += (double)(h->cap_f_npad + RIDE) * (double)h->cap_f_npad * sizeof(float);
+    *value = b;
+    return SIGP_OK;
+  }
+  return fail(h, SIGP_BAD_ARG, "get_stat: unknown name %s", name);
+}
+
 int sigp_profile(sigp_handle* h, int enable) {
   if (!h) return SIGP_BAD_ARG;
   if (!enable) prof_drain(h);
@@ -1720,230 +1857,8 @@ int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* laun
   return SIGP_OK;
 }
 
-// fp64 MFMA issue-rate probe: nothing but v_mfma_f64_16x16x4_f64 on 16 independent accumulators per wave
-__global__ __launch_bounds__(256, 2) void mfma_peak_kernel(double* out, int iters, double seed) {
-  sigp::d4 acc[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = sigp::d4{0.0, 0.0, 0.0, 0.0};
-  double a[8], b[8];
-  unsigned long long x = 88172645463325252ull + threadIdx.x * 2654435761ull + blockIdx.x * 97ull;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {   // seed < 0: full-range pseudo-random operands (data toggling); else constants
-    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-    a[i] = seed < 0 ? (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5 : seed + threadIdx.x * 1e-3;
-    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
-    b[i] = seed < 0 ? (double)(long long)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5 : seed - threadIdx.x * 1e-3;
-  }
-  for (int it = 0; it < iters; ++it) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i & 7], b[(i + (i >> 3)) & 7], acc[i], 0, 0, 0);
-  }
-  double s = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
-  out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-
-__global__ void whereami_kernel(unsigned* out) {
-  // hold the CU for a while so that blocks spread over every CU the mask allows
-  long long t0 = clock64();
-  while (clock64() - t0 < 200000) {}
-  if (threadIdx.x == 0) {
-    unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID, 32 bits
-    unsigned hwid = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
-    out[2 * blockIdx.x] = xcc;
-    out[2 * blockIdx.x + 1] = hwid;
-  }
-}
-
-// ---- debug / micro-benchmark entry points (not part of the product ABI; see tools/) -------------------
-int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps, double* ms_avg, double* L_out, double* Linv_out) {
-  if (!h || !A128 || reps < 1 || reps > 4096) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  // `reps` copies of the block are factored by `reps` back-to-back launches between two events (a lone 60 us launch on
-  // an idle GPU is timed at whatever clock the chip idles at); 20 untimed launches first
-  double *a0, *a1, *li; int* info;
-  HIPCHK(h, hipMalloc((void**)&a0, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&a1, (size_t)reps * NB * NB * 8));
-  HIPCHK(h, hipMalloc((void**)&li, NB * NB * 8)); HIPCHK(h, hipMalloc((void**)&info, 4));
-  HIPCHK(h, hipMemset(li, 0, NB * NB * 8));
-  HIPCHK(h, hipMemcpy(a0, A128, NB * NB * 8, hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemset(info, 0, 4));
-  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  hipStream_t st = h->slots[0].s_upd;
-  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  float ms = 0;
-  for (int pass = 0; pass < 2; ++pass) {
-    for (int r = 0; r < reps; ++r) HIPCHK(h, hipMemcpyAsync(a1 + (size_t)r * NB * NB, a0, NB * NB * 8, hipMemcpyDeviceToDevice, st));
-    const int n = pass == 0 ? std::min(reps, 20) : reps;
-    HIPCHK(h, hipEventRecord(e0, st));
-    for (int r = 0; r < n; ++r)
-      hipLaunchKernelGGL(potrf_diag_kernel<double>, dim3(1), dim3(DIAG_THREADS), DIAG_LDS_BYTES, st, a1 + (size_t)r * NB * NB, (long)NB, li, info, 0, skip, 0L, 0L);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-  }
-  if (ms_avg) *ms_avg = ms / reps;
-  if (L_out) HIPCHK(h, hipMemcpy(L_out, a1, NB * NB * 8, hipMemcpyDeviceToHost));
-  if (Linv_out) HIPCHK(h, hipMemcpy(Linv_out, li, NB * NB * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(a0); (void)hipFree(a1); (void)hipFree(li); (void)hipFree(info);
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return SIGP_OK;
-}
-
-// time kbuild_kernel for nb lockstep members of order n (flags: 2 no covariance function, 4 no store)
-int sigp_debug_time_kbuild(sigp_handle* h, int n, int d, int nb, int kernel_id, int flags, int reps, double* ms_avg) {
-  if (!h || n < 128 || n % 128 || d < 1 || d > 64 || nb < 1 || reps < 1) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const long dp = round_up(d, 8), ld = n;
-  double *X, *Mat; KParams* kps;
-  HIPCHK(h, hipMalloc((void**)&X, (size_t)n * dp * 8)); HIPCHK(h, hipMalloc((void**)&Mat, (size_t)nb * n * n * 8));
-  HIPCHK(h, hipMalloc((void**)&kps, (size_t)nb * sizeof(KParams)));
-  std::vector<double> hx((size_t)n * dp, 0.0);
-  for (long i = 0; i < n; ++i) for (int p = 0; p < d; ++p) hx[i * dp + p] = 1e-3 * (double)(((i * dp + p) * 2654435761u) % 4000) - 2.0;
-  HIPCHK(h, hipMemcpy(X, hx.data(), hx.size() * 8, hipMemcpyHostToDevice));
-  std::vector<KParams> hk((size_t)nb, make_kparams(kernel_id, std::sqrt((double)d), 1e-2, 0));
-  HIPCHK(h, hipMemcpy(kps, hk.data(), hk.size() * sizeof(KParams), hipMemcpyHostToDevice));
-  hipStream_t st = h->slots[0].s_upd;
-  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  double tot = 0;
-  for (int r = 0; r < reps + 2; ++r) {
-    HIPCHK(h, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(kbuild_kernel<double>, dim3((unsigned)kbuild_tiles(n), 1, (unsigned)nb), dim3(256), 0, st, X, 0L, (int)dp, d, n, Mat,
-                       (long)n * n, ld, kps, flags & ~1);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    if (r >= 2) tot += ms;
-  }
-  if (ms_avg) *ms_avg = tot / reps;
-  (void)hipFree(X); (void)hipFree(Mat); (void)hipFree(kps); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return SIGP_OK;
-}
-
-int sigp_debug_mfma_peak(sigp_handle* h, int blocks, int iters, double* tflops, double seed) {
-  if (!h || blocks < 1 || iters < 1) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  double* out; HIPCHK(h, hipMalloc((void**)&out, (size_t)blocks * 256 * 8));
-  hipStream_t st = h->slots[0].s_pan;
-  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  float best = 1e30f;
-  for (int r = 0; r < 5; ++r) {
-    HIPCHK(h, hipEventRecord(e0, st));
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st, out, iters, seed);
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    if (r > 0 && ms < best) best = ms;
-  }
-  if (tflops) *tflops = (double)blocks * 4 * iters * 16 * 2048.0 / (best * 1e-3) / 1e12;
-  (void)hipFree(out); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return SIGP_OK;
-}
-
-// time the lower-tile update C -= P P^T (128x128 tiles) on a synthetic (rt*128) x K panel, tile walk `patch`
-}  // extern "C" (templates need C++ linkage)
-
-template <typename Real>
-static int debug_time_syrk_t(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
-  if (!h || rt < 1 || K < 16 || reps < 1) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  const long n = (long)rt * NB, ldp = K, ldc = n;
-  Real *P, *Cm;
-  HIPCHK(h, hipMalloc((void**)&P, (size_t)n * K * sizeof(Real))); HIPCHK(h, hipMalloc((void**)&Cm, (size_t)n * n * sizeof(Real)));
-  HIPCHK(h, hipMemset(Cm, 0, (size_t)n * n * sizeof(Real)));
-  std::vector<Real> hp((size_t)n * K);
-  for (size_t i = 0; i < hp.size(); ++i) hp[i] = (Real)(1e-3 * (double)((i * 2654435761u) % 1000) - 0.5);
-  HIPCHK(h, hipMemcpy(P, hp.data(), hp.size() * sizeof(Real), hipMemcpyHostToDevice));
-  hipStream_t st = h->slots[0].s_pan;
-  hipEvent_t e0, e1; HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-  GemmArgsT<Real> g{};
-  g.A = P; g.lda = ldp; g.B = P; g.ldb = ldp; g.C = Cm; g.ldc = ldc; g.K = K; g.r0 = 0; g.r1 = rt; g.c0 = 0; g.c1 = rt; g.lower = 1; g.patch = patch; g.dbg = dbg;
-  unsigned long long* stamp = nullptr;
-  const int ngrid = gemm_grid_size(0, rt, 0, rt, 1, patch);
-  if (clock_ghz && small == 2) { HIPCHK(h, hipMalloc((void**)&stamp, (size_t)ngrid * 40)); HIPCHK(h, hipMemset(stamp, 0, (size_t)ngrid * 40)); g.stamp = stamp; }
-  if (small == 1) { g.r1 *= 2; g.c1 *= 2; }
-  double tot = 0;
-  for (int r = 0; r < reps + 2; ++r) {
-    HIPCHK(h, hipEventRecord(e0, st));
-    int rc = small == 1 ? launch_gemm_cfg<Real, 64, 64, 2, 2, GEMM_SUB, false>(h, st, g) : small == 2 ? launch_syrk128_t<Real, false>(h, st, g) : launch_gemm_cfg<Real, 128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
-    if (rc) return rc;
-    HIPCHK(h, hipEventRecord(e1, st));
-    HIPCHK(h, hipStreamSynchronize(st));
-    float ms; HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
-    if (r >= 2) tot += ms;
-  }
-  if (stamp) {
-    std::vector<unsigned long long> hs((size_t)ngrid * 5);
-    HIPCHK(h, hipMemcpy(hs.data(), stamp, hs.size() * 8, hipMemcpyDeviceToHost));
-    if (dbg & 256) {
-      double p0 = 0, p1 = 0, p2 = 0;
-      for (int i = 0; i < ngrid; ++i) { p0 += (double)hs[2 * (size_t)ngrid + 3 * i]; p1 += (double)hs[2 * (size_t)ngrid + 3 * i + 1]; p2 += (double)hs[2 * (size_t)ngrid + 3 * i + 2]; }
-      fprintf(stderr, "[syrk phases] cycles per tile (wave 0): prologue %.0f  K loop %.0f  epilogue %.0f\n", p0 / ngrid, p1 / ngrid, p2 / ngrid);
-    }
-    double sc = 0, sr = 0;
-    for (int i = 0; i < ngrid; ++i) { sc += (double)hs[2 * i]; sr += (double)(hs[2 * i + 1] >> 8); }
-    if (dbg & 32) { fprintf(stderr, "[xcc by block]"); for (int i = 0; i < std::min(ngrid, 96); ++i) fprintf(stderr, " %d", (int)(hs[2 * i + 1] & 0xf)); fprintf(stderr, "\n"); }
-    *clock_ghz = sr > 0 ? sc / (sr * 10.0) : 0.0;   // s_memrealtime ticks at 100 MHz
-    (void)hipFree(stamp);
-  }
-  const double nt = (double)rt * (rt + 1) / 2;
-  if (ms_avg) *ms_avg = tot / reps;
-  if (tflops) *tflops = nt * 2.0 * NB * NB * K / (tot / reps * 1e-3) / 1e12;
-  (void)hipFree(P); (void)hipFree(Cm); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-  return SIGP_OK;
-}
-
-extern "C" {
-
-// small: 0 generic 128-tile kernel, 1 generic 64-tile kernel, 2 syrk128_kernel; +16: the fp32 instantiation
-int sigp_debug_time_syrk(sigp_handle* h, int rt, int K, int patch, int small, int reps, double* ms_avg, double* tflops, int dbg, double* clock_ghz) {
-  if (small & 16) return debug_time_syrk_t<float>(h, rt, K, patch, small & 15, reps, ms_avg, tflops, dbg, clock_ghz);
-  return debug_time_syrk_t<double>(h, rt, K, patch, small, reps, ms_avg, tflops, dbg, clock_ghz);
-}
-
-// do independent small kernels on different streams of this handle overlap?  returns wall ms for nstreams x reps launches
-int sigp_debug_stream_concurrency(sigp_handle* h, int nstreams, int reps, int blocks, int iters, int use_slot_streams, double* ms_out) {
-  if (!h || nstreams < 1 || nstreams > 16) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<hipStream_t> st((size_t)nstreams);
-  for (int i = 0; i < nstreams; ++i) {
-    if (use_slot_streams) {
-      int rc = slot_init(h, h->slots[i / 2]);
-      if (rc) return rc;
-      st[i] = (i & 1) ? h->slots[i / 2].s_pan : h->slots[i / 2].s_upd;
-    } else {
-      HIPCHK(h, hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking));
-    }
-  }
-  double* out; HIPCHK(h, hipMalloc((void**)&out, (size_t)nstreams * blocks * 256 * 8));
-  HIPCHK(h, hipDeviceSynchronize());
-  auto t0 = std::chrono::steady_clock::now();
-  for (int r = 0; r < reps; ++r)
-    for (int i = 0; i < nstreams; ++i)
-      hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, st[i], out + (size_t)i * blocks * 256, iters, 0.25);
-  HIPCHK(h, hipDeviceSynchronize());
-  if (ms_out) *ms_out = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-  if (!use_slot_streams) for (auto q : st) (void)hipStreamDestroy(q);
-  (void)hipFree(out);
-  return SIGP_OK;
-}
-
-// which XCC / CU does CU-mask bit `bit` select?  out[0] = XCC_ID reg, out[1] = HW_ID reg of a 1-block kernel
-int sigp_debug_cumask_probe(sigp_handle* h, const unsigned* mask8, int blocks, unsigned* out2) {
-  if (!h || !mask8 || blocks < 1 || !out2) return SIGP_BAD_ARG;
-  HIPCHK(h, hipSetDevice(h->device));
-  hipStream_t st;
-  HIPCHK(h, hipExtStreamCreateWithCUMask(&st, 8, mask8));
-  unsigned* d; HIPCHK(h, hipMalloc((void**)&d, (size_t)blocks * 8));
-  HIPCHK(h, hipMemset(d, 0xff, (size_t)blocks * 8));
-  HIPCHK(h, hipDeviceSynchronize());
-  hipLaunchKernelGGL(whereami_kernel, dim3(blocks), dim3(64), 0, st, d);
-  HIPCHK(h, hipStreamSynchronize(st));
-  HIPCHK(h, hipMemcpy(out2, d, (size_t)blocks * 8, hipMemcpyDeviceToHost));
-  (void)hipFree(d); (void)hipStreamDestroy(st);
-  return SIGP_OK;
-}
+#ifdef SIGP_DEBUG_TOOLS
+#include "sigp_debug.inc"
+#endif
 
 }  // extern "C"

@@ -1,0 +1,170 @@
+// The reference's OWN kernel at the reference's OWN size (n <= 128 training years, any number of features), batched:
+// one workgroup per fit, everything in LDS.  Replaces, per (region, year, grid point),
+//     north/June1st.py:264-277   (expm -> X Sigma~ X^T + sn~ I -> cholesky -> A~ -> sigma_f -> k*, k** -> v -> fmean, fvar)
+//     north/June1st.py:246       (nlML)
+// for the retro loop (north/retrospective_forecasts/September1st_retro.py:176-248) times the 20 x 20 hyper-parameter
+// grid of north/June1st.py:210-211 -- ~5e4 fits of order <= 45 that are launch-latency bound one at a time.
+//
+// Covariance in factored form.  M is symmetric negative semi-definite, M = Q diag(lam) Q^T, so
+//     Sigma~(l) = expm(l M) = Q diag(exp(l lam)) Q^T,        K~ = (X Q) diag(exp(l lam)) (X Q)^T + sn~ I :
+// a data set is staged ONCE as A = [X ; Xs] Q (rows 0..n-1 training, rows n.. test points) with lam, and every grid point
+// of that data set rebuilds K~ from A with its own weights (one eigendecomposition per data set).
+// lam_mode 1: the weights are given directly (w_k = lam_k >= 0): A = [X ; Xs] U, lam = eigenvalues of a host-side
+// Sigma~ = U diag(lam) U^T -- this is how a Pade expm(l M) from the host (the reference's own numbers at extreme l,
+// SURVEY App. C-11) goes through the same kernel.
+//
+// Layout in LDS: augmented lower-trapezoid  Kp[(n + 1 + m)][ldk]: rows 0..n-1 = K~ (lower), row n = y, rows n+1.. = k~*_j.
+// A right-looking column Cholesky of the bordered matrix leaves  z = L~^-1 y  in row n and  v_j = L~^-1 k~*_j  below it
+// (the same ride-along trick as the blocked path), so sigma_f = z.z/n, fmean_j = v_j.z, fvar_j = sigma_f (k~** + sn~ - v_j.v_j).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace sigp {
+
+constexpr int SM_NMAX = 128;   // largest order one workgroup handles
+constexpr int SM_MMAX = 8;     // test points per fit
+
+struct SmallSet {
+  long a_off;      // doubles into the A pool: A [(n + m)][N] row-major
+  long y_off;      // doubles into the y pool: y [n]
+  long lam_off;    // doubles into the lam pool: lam [N]
+  int n, N, m;
+  int lam_mode;    // 0: w_k = exp(ell * lam_k);  1: w_k = max(lam_k, 0)
+};
+struct SmallProb {
+  int set;         // data set of this fit
+  int pad;
+  double ell;      // length scale (lam_mode 0)
+  double sn;       // sigma_n tilde
+};
+
+inline long smallgp_lds_bytes(int n, int m, int ch) {
+  const long ldk = n | 1;
+  return ((long)(n + 1 + m) * ldk + (long)(n + m) * (ch + 1) + ch + 4 * SM_MMAX + 16) * (long)sizeof(double);
+}
+
+// sum over the 256 threads; result valid on every thread
+__device__ inline double smallgp_allsum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// out [nprob][4] = sigma_f, nlML, info (LAPACK pivot index, 0 = ok), sigma_n;  mean / var [nprob][mstride]
+__global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict__ sets, const SmallProb* __restrict__ probs,
+                                                      const double* __restrict__ Apool, const double* __restrict__ ypool,
+                                                      const double* __restrict__ lampool, int ch, double* __restrict__ out,
+                                                      double* __restrict__ mean, double* __restrict__ var, int mstride) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const SmallProb pb = probs[blockIdx.x];
+  const SmallSet st = sets[pb.set];
+  const int n = st.n, N = st.N, m = st.m;
+  const int R = n + 1 + m;          // rows of the bordered matrix
+  const int ldk = n | 1;            // odd pitch: column walks spread over the banks
+  const int lda = ch + 1;
+  double* Kp = (double*)smem_raw;                 // [R][ldk]
+  double* Ac = Kp + (long)R * ldk;                // [n + m][ch + 1]: feature chunk, pre-scaled by sqrt(w_k)
+  double* wk = Ac + (long)(n + m) * lda;          // [ch]
+  double* kss = wk + ch;                          // [SM_MMAX] k~**_j
+  double* red = kss + SM_MMAX;                    // reduction scratch
+  __shared__ int s_info;
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const double* A = Apool + st.a_off;
+  const double* lam = lampool + st.lam_off;
+
+  for (int e = tid; e < R * ldk; e += 256) Kp[e] = 0.0;
+  if (tid < SM_MMAX) kss[tid] = 0.0;
+  if (tid == 0) s_info = 0;
+
+  // ---- K~ (lower), k~*, k~** from the factored covariance, ch features at a time --------------------------------
+  for (int k0 = 0; k0 < N; k0 += ch) {
+    const int kc = min(ch, N - k0);
+    __syncthreads();
+    if (tid < kc) {
+      const double l = lam[k0 + tid];
+      wk[tid] = sqrt(st.lam_mode ? fmax(l, 0.0) : exp(pb.ell * l));
+    }
+    __syncthreads();
+    for (int e = tid; e < (n + m) * kc; e += 256) {
+      const int r = e / kc, k = e - r * kc;
+      Ac[r * lda + k] = A[(long)r * N + k0 + k] * wk[k];
+    }
+    __syncthreads();
+    for (int i = ty; i < n + m; i += 16) {
+      const int krow = i < n ? i : i + 1;               // test rows sit below the y row
+      const double* ai = Ac + i * lda;
+      const int jmax = i < n ? i : n - 1;
+      for (int j = tx; j <= jmax; j += 16) {
+        const double* aj = Ac + j * lda;
+        double acc = 0.0;
+        for (int k = 0; k < kc; ++k) acc = fma(ai[k], aj[k], acc);
+        Kp[krow * ldk + j] += acc;
+      }
+    }
+    if (tid < m) {
+      const double* as = Ac + (n + tid) * lda;
+      double acc = 0.0;
+      for (int k = 0; k < kc; ++k) acc = fma(as[k], as[k], acc);
+      kss[tid] += acc;
+    }
+  }
+  __syncthreads();
+  if (tid < n) {
+    Kp[tid * ldk + tid] += pb.sn;
+    Kp[n * ldk + tid] = ypool[st.y_off + tid];
+  }
+  __syncthreads();
+
+  // ---- right-looking Cholesky of the bordered matrix, one column per step --------------------------------------
+  for (int j = 0; j < n; ++j) {
+    double d = Kp[j * ldk + j];
+    if (!(d > 0.0)) {               // non-positive or NaN pivot: LAPACK info = 1-based index of the first one
+      if (tid == 0 && s_info == 0) s_info = j + 1;
+      d = 1.0;
+    }
+    const double s = sqrt(d), inv = 1.0 / s;
+    __syncthreads();                // everyone has read the pivot
+    for (int i = j + tid; i < R; i += 256) Kp[i * ldk + j] = (i == j) ? s : Kp[i * ldk + j] * inv;
+    __syncthreads();
+    for (int i = j + 1 + ty; i < R; i += 16) {
+      const double lij = Kp[i * ldk + j];
+      const int cmax = i < n ? i : n - 1;
+      for (int c = j + 1 + tx; c <= cmax; c += 16) Kp[i * ldk + c] = fma(-lij, Kp[c * ldk + j], Kp[i * ldk + c]);
+    }
+    __syncthreads();
+  }
+
+  // ---- reductions: sigma_f, nlML, mean, variance (north/June1st.py:267-268, 246, 276-277) ------------------------
+  const double* z = Kp + n * ldk;
+  const double zi = tid < n ? z[tid] : 0.0;
+  const double zz = smallgp_allsum(zi * zi, red);
+  const double logdet = smallgp_allsum(tid < n ? log(Kp[tid * ldk + tid]) : 0.0, red);
+  const int info = s_info;
+  const double inf = __builtin_huge_val(), qnan = __builtin_nan("");
+  const double sf = zz / (double)n;
+  if (tid == 0) {
+    double* o = out + (long)blockIdx.x * 4;
+    if (info == 0) {
+      o[0] = sf;
+      o[1] = 0.5 * n + logdet + 0.5 * n * log(sf) + 0.5 * n * log(2.0 * M_PI);
+      o[2] = 0.0;
+      o[3] = sf * pb.sn;
+    } else {
+      o[0] = inf; o[1] = inf; o[2] = (double)info; o[3] = inf;
+    }
+  }
+  for (int j = 0; j < m; ++j) {
+    const double vi = tid < n ? Kp[(n + 1 + j) * ldk + tid] : 0.0;
+    const double vz = smallgp_allsum(vi * zi, red);
+    const double vv = smallgp_allsum(vi * vi, red);
+    if (tid == 0) {
+      mean[(long)blockIdx.x * mstride + j] = info == 0 ? vz : qnan;
+      var[(long)blockIdx.x * mstride + j] = info == 0 ? sf * (kss[j] + pb.sn - vv) : qnan;
+    }
+  }
+}
+
+}  // namespace sigp

@@ -32,7 +32,9 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
 template <typename T, bool SET>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
-                                             long ldc, int K, int dbg, T* As, T* Bs, bool stamp, unsigned long long& ph0, unsigned long long& ph1) {
+                                             long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1) {
+  const int dbg = dbg_in & DBG_MASK;            // ablation bits: debug library only
+  const bool stamp = stamp_in && DBG_MASK != 0;
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v16_t v16_t;
@@ -193,19 +195,20 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
   T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
   unsigned long long st_c0 = 0, st_r0 = 0;
-  if (g.stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  unsigned long long* const stamp = DBG_MASK ? g.stamp : nullptr;
+  if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   unsigned long long ph0 = 0, ph1 = 0;
-  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, g.stamp != nullptr, ph0, ph1);
-  if (g.stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
+  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1);
+  if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
     __builtin_amdgcn_s_waitcnt(0);
     if (tid == 0) {
-      unsigned long long* o = g.stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
+      unsigned long long* o = stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
       o[0] = ph0 - st_c0; o[1] = ph1 - ph0; o[2] = __builtin_amdgcn_s_memtime() - ph1;
     }
   }
-  if (g.stamp && tid == 0) {
-    g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
-    g.stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+  if (stamp && tid == 0) {
+    stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
+    stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
   }
 }
 

@@ -240,11 +240,14 @@ class GPR:
         Returns the scipy ``OptimizeResult``; afterwards the handle is fitted at ``exp(result.x)``."""
         from scipy.optimize import minimize
 
-        def fun(th):
-            v, g = self.nlml(th, grad=grad)
-            return float(v), np.asarray(g, dtype=np.float64)
+        if grad is None:                  # value only: scipy differences it numerically
+            res = minimize(lambda th: float(self.nlml(th, grad=None)[0]), np.asarray(theta0, dtype=np.float64), method=method, jac=False, **kw)
+        else:
+            def fun(th):
+                v, g = self.nlml(th, grad=grad)
+                return float(v), np.asarray(g, dtype=np.float64)
 
-        res = minimize(fun, np.asarray(theta0, dtype=np.float64), method=method, jac=True, **kw)
+            res = minimize(fun, np.asarray(theta0, dtype=np.float64), method=method, jac=True, **kw)
         if np.all(np.isfinite(res.x)):
             try:
                 self.refit(float(np.exp(res.x[0])), float(np.exp(res.x[1])))
@@ -253,6 +256,21 @@ class GPR:
         return res
 
     # ---- state accessors -----------------------------------------------------------------------
+    def _stat(self, name):
+        v = C.c_double()
+        self._check(self._lib.sigp_get_stat(self._h, name.encode(), C.byref(v)), "get_stat")
+        return v.value
+
+    @property
+    def refine_residual_(self):
+        """fp32 engine: max|y - K~ alpha~| / max|y| after the last fp64 refinement step of the last fit."""
+        return self._stat("refine_residual")
+
+    @property
+    def matrix_bytes_(self):
+        """Device bytes this handle holds in matrix / factor buffers."""
+        return self._stat("matrix_bytes")
+
     @property
     def alpha_(self):
         """alpha = K^-1 y = A~/sigma_f (north/June1st.py:271), shape (n, 1)."""
@@ -292,12 +310,17 @@ class GPR:
         return out
 
     # ---- batches (retro loop :176-248, grid :210-211) ------------------------------------------
-    def fit_batch(self, X, y, Xs, ell, sn_tilde, concurrency=2, group=8):
-        """Independent fits sharing (n, d, m).  X [B,n,d] (or [n,d] shared), y [B,n] (or [n]), Xs [B,m,d]
-        (or [m,d] / None), ell [F], sn_tilde [F]; F fits, fit i uses data set i % B.  RBF / Matern only.
-        Returns dict(sigma_f, nlml, info, sigma_n, mean [F,m], var [F,m])."""
+    def fit_batch(self, X, y, Xs, ell, sn_tilde, concurrency=2, group=8, M=None):
+        """Independent fits.  X [B,n,d] (or [n,d] shared), y [B,n] (or [n]), Xs [B,m,d] (or [m,d] / None), ell [F],
+        sn_tilde [F]; F fits, fit i uses data set i % B.
+        Returns dict(sigma_f, nlml, info, sigma_n, mean [F,m], var [F,m]).
+
+        RBF / Matern: lockstep groups on the blocked engine (data sets share (n, d, m)).
+        Reference kernel: X / y / Xs may also be LISTS of arrays of different shapes (the retro years: n grows with the
+        year); fits of order n <= 128 run one workgroup per fit in a single launch (``smallbatch.SmallBatch``), with
+        Sigma~ = expm(l M) formed as this engine's ``expm`` option says; larger ones go one at a time through ``fit``."""
         if self.kernel == "netdiffusion":
-            raise NotImplementedError("fit_batch: the reference kernel batches on the host loop (retro.retro_forecast)")
+            return self._fit_batch_netdiffusion(X, y, Xs, ell, sn_tilde, M)
         X = L.f64(X)
         shared = X.ndim == 2
         Xb = X[None] if shared else X
@@ -319,6 +342,48 @@ class GPR:
         self._check(self._lib.sigp_batch_upload(self._h, B, L.ptr(Xb), n * d, L.ptr(yb), n, L.ptr(Xsb), m * d, n, d, m), "batch_upload")
         self._batch_m = m
         return self.run_batch(0, F, ell, sn, concurrency, group)
+
+    def _fit_batch_netdiffusion(self, X, y, Xs, ell, sn_tilde, M=None):
+        from .smallbatch import SmallBatch, NMAX, MMAX
+        if isinstance(X, np.ndarray) and X.ndim == 2:
+            X, y, Xs, M = [X], [y], [Xs], [M]
+        B = len(X)
+        Xs = [None] * B if Xs is None else list(Xs)
+        M = [None] * B if M is None else list(M)
+        ell = np.atleast_1d(np.asarray(ell, dtype=np.float64)); sn = np.atleast_1d(np.asarray(sn_tilde, dtype=np.float64))
+        F = len(ell)
+        if len(sn) != F:
+            raise ValueError("ell and sn_tilde must have the same length")
+        mmax = max([0] + [np.atleast_2d(x).shape[0] for x in Xs if x is not None])
+        res = dict(sigma_f=np.zeros(F), nlml=np.zeros(F), info=np.zeros(F, np.int64), sigma_n=np.zeros(F),
+                   mean=np.full((F, mmax), np.nan), var=np.full((F, mmax), np.nan))
+        small = [i for i in range(F) if np.asarray(X[i % B]).shape[0] <= NMAX and (Xs[i % B] is None or np.atleast_2d(Xs[i % B]).shape[0] <= MMAX)]
+        if small:
+            sb = SmallBatch(self)
+            ids = {}
+            for i in small:
+                b = i % B
+                if b not in ids:
+                    ids[b] = sb.add_dataset(X[b], y[b], Xs[b], M[b])
+                sb.add_fit(ids[b], ell[i], sn[i], expm=self._expm)
+            r = sb.run()
+            for k in ("sigma_f", "nlml", "info", "sigma_n"):
+                res[k][small] = r[k]
+            res["mean"][small, :r["mean"].shape[1]] = r["mean"]
+            res["var"][small, :r["var"].shape[1]] = r["var"]
+        for i in (i for i in range(F) if i not in set(small)):          # orders beyond one workgroup: the blocked engine, one fit at a time
+            b = i % B
+            try:
+                self.fit(X[b], y[b], ell[i], sn[i], M=M[b], Xs=Xs[b])
+                res["sigma_f"][i], res["nlml"][i], res["sigma_n"][i] = self.sigma_f_, self.nlml_, self.sigma_n_
+                if Xs[b] is not None:
+                    mu, var = self.predict(Xs[b])
+                    res["mean"][i, :len(mu)], res["var"][i, :len(var)] = mu, var
+            except LinAlgError as e:
+                res["sigma_f"][i] = res["nlml"][i] = res["sigma_n"][i] = np.inf
+                res["info"][i] = e.info
+        self._fitted = False
+        return res
 
     def upload_batch(self, X, y, Xs, group=8, concurrency=1):
         """Stage data sets in HBM and allocate the lockstep slots without running any fit (bench warm-up)."""
@@ -354,13 +419,17 @@ class GPR:
         return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
                     mean=mean[:, :mdim], var=var[:, :mdim])
 
-    def nlml_grid(self, X, y, ells, sns, concurrency=2, group=8):
+    def nlml_grid(self, X, y, ells, sns, concurrency=2, group=8, M=None):
         """nlML on the (l, sn~) grid for one data set -- the offline 20x20 search implied by
-        north/June1st.py:210-211.  Returns [len(ells), len(sns)], +inf where K~ is not SPD."""
+        north/June1st.py:210-211 (``ells = LGRID, sns = SGRID`` with the reference kernel reproduces it: one launch,
+        one workgroup per grid point).  Returns [len(ells), len(sns)], +inf where K~ is not SPD."""
         ells = np.asarray(ells, dtype=np.float64).reshape(-1)
         sns = np.asarray(sns, dtype=np.float64).reshape(-1)
         E, S = np.meshgrid(ells, sns, indexing="ij")
-        r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency, group=group)
+        if self.kernel == "netdiffusion":
+            r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), M=M)
+        else:
+            r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency, group=group)
         return r["nlml"].reshape(len(ells), len(sns))
 
     # ---- measurement ---------------------------------------------------------------------------

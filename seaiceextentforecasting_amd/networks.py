@@ -25,7 +25,8 @@ class Network:
         self.dimX, self.dimY, self.dimT = self.data.shape
         self.V = {}
         self.A = {}
-        self.corrs = []
+        self._R = None
+        self._active = None
         self.tau = 0            # shadows the method on instances, exactly like the reference (:23)
         self.nodes = []
         self.unavail = []
@@ -34,28 +35,42 @@ class Network:
         self.strength = {}
         self.strengthmap = []
 
-    # ---- ComplexNetworks.py:31-47 -------------------------------------------------------------------------
-    def tau(self, significance=0.01):
-        """Cell-to-cell correlations and the threshold tau = mean of the significantly positive ones
-        (one-sided t-test, df = T-2)."""
+    # ---- threshold (behaviour of ComplexNetworks.py:31-47) ------------------------------------------------
+    def tau(self, significance=0.01, engine=None):
+        """Correlation threshold of the network: the mean of the cell-to-cell correlations that are positive and
+        significant under a one-sided t-test with T-2 degrees of freedom.
+
+        Active cells are those with any non-zero anomaly (``|nanmax| > 0``), taken in row-major order; ``nodes`` holds
+        their flat indices.  Only the N x N matrix of pairwise correlations is kept (``area_level`` reads nothing
+        else); the reference's N x dimX x dimY scatter of it is available on demand as ``corrs``.
+        ``engine``: an optional ``GPR`` handle -- the correlation matrix and the thresholded mean are then formed on
+        the GPU (``sigp_corr_tau``: one fp64 MFMA product of the standardised series + a fused reduction)."""
         with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            ID = np.where(np.abs(np.nanmax(self.data, 2)) > 0)
-        N = np.shape(ID)[1]
-        R = np.corrcoef(self.data[ID])
-        np.fill_diagonal(R, np.nan)
-        self._R = R.copy()                                     # N x N, NaN diagonal: the only correlations ever used
-        self.nodes = np.atleast_2d(ID[0] * self.dimY + ID[1])
-        self._node_index = {int(v): n for n, v in enumerate(self.nodes[0, :])}
-        self.corrs = np.zeros((N, self.dimX, self.dimY)) * np.nan
-        for n in range(N):                                     # row-wise scatter: 7x faster than one fancy assignment
-            self.corrs[n, :, :][ID] = R[n, :]
-        df = self.dimT - 2
-        R = R[R >= 0]
-        T = R * np.sqrt(df / (1 - R ** 2))
-        P = stats.t.sf(T, df)
-        R = R[P < significance]
-        self.tau = np.mean(R)
+            warnings.simplefilter("ignore")                   # all-NaN (land) cells
+            active = np.abs(np.nanmax(self.data, axis=2)) > 0
+        rows, cols = np.nonzero(active)
+        self._active = (rows, cols)
+        self.nodes = np.atleast_2d(rows * self.dimY + cols)
+        self._node_index = {int(flat): k for k, flat in enumerate(self.nodes[0])}
+        series = self.data[rows, cols, :]                     # [N, T]
+        dof = self.dimT - 2
+        if engine is not None:
+            self._R, self.tau = engine.corr_tau(series, dof, significance)
+            return
+        R = np.corrcoef(series)
+        np.fill_diagonal(R, np.nan)                           # a cell is not its own neighbour
+        self._R = R
+        self.tau = significant_positive_mean(R, dof, significance)
+
+    @property
+    def corrs(self):
+        """[N, dimX, dimY]: map of every active cell's correlation with every other cell, NaN elsewhere
+        (the attribute the reference materialises in ``tau``; built here only when somebody asks for it)."""
+        if self._R is None:
+            return []
+        maps = np.full((self._R.shape[0], self.dimX, self.dimY), np.nan)
+        maps[:, self._active[0], self._active[1]] = self._R
+        return maps
 
     # ---- ComplexNetworks.py:49-281 ------------------------------------------------------------------------
     def area_level(self, latlon_grid=False):
@@ -208,30 +223,49 @@ class Network:
         self.A = self.V
         self.unavail = unavail_list
 
-    # ---- ComplexNetworks.py:283-326 -----------------------------------------------------------------------
+    # ---- area series and links (behaviour of ComplexNetworks.py:283-326) -----------------------------------
     def intra_links(self, area=None, lat=None):
-        """Area anomaly series (the GP's features), covariance links and strength map."""
-        self.anomaly, self.links, self.strength = {}, {}, {}
-        self.strengthmap = np.zeros((self.dimX, self.dimY)) * np.nan
+        """Per-area anomaly series (the GP's features): the sum over an area's cells of the cell series weighted by
+        sqrt(cell area) (or sqrt(cos lat) on a lat-lon grid); ``links`` = covariance between area series (0 on the
+        diagonal), ``strength`` = sum of |links|, painted onto the cells as ``strengthmap``."""
         if lat is not None:
-            scale = np.sqrt(np.cos(np.radians(lat)))
+            weight = np.sqrt(np.cos(np.radians(lat)))
         elif area is not None:
-            scale = np.sqrt(area)
+            weight = np.sqrt(area)
         else:
-            scale = np.ones((self.dimX, self.dimY))
-        for A in self.V:
-            temp_array = np.zeros(self.data.shape) * np.nan
-            for cell in self.V[A]:
-                temp_array[cell[0], cell[1], :] = np.multiply(self.data[cell[0], cell[1], :], scale[cell[0], cell[1]])
-            self.anomaly[A] = np.nansum(temp_array, axis=(0, 1))
-        keys = list(self.anomaly)
-        sd = {A: np.std(self.anomaly[A]) for A in keys}
-        for A in keys:
-            self.links[A] = [0 if A2 == A else stats.pearsonr(self.anomaly[A], self.anomaly[A2])[0] * (sd[A] * sd[A2]) for A2 in keys]
-        for A in self.links:
-            self.strength[A] = np.nansum([abs(v) for v in self.links[A]])
-            for cell in self.V[A]:
-                self.strengthmap[cell[0], cell[1]] = self.strength[A]
+            weight = np.ones((self.dimX, self.dimY))
+        ids = list(self.V)
+        series = np.zeros((len(ids), self.dimT))
+        for row, A in enumerate(ids):
+            # unique cells in row-major order, accumulated one after the other: the same additions in the same order as
+            # a NaN-padded cube reduced over its two leading axes, without building that cube per area
+            flat = np.unique([c[0] * self.dimY + c[1] for c in self.V[A]])
+            cx, cy = np.divmod(flat, self.dimY)
+            contrib = self.data[cx, cy, :] * weight[cx, cy][:, None]
+            series[row] = np.add.reduce(np.where(np.isnan(contrib), 0.0, contrib), axis=0)
+        self.anomaly = {A: series[row].copy() for row, A in enumerate(ids)}
+        if len(ids) > 1:
+            # pearson r x sd_a x sd_b (population sd) is the population covariance
+            cov = np.atleast_2d(np.cov(series, bias=True))
+        else:
+            cov = np.zeros((len(ids), len(ids)))
+        np.fill_diagonal(cov, 0.0)
+        self.links = {A: [0 if j == row else cov[row, j] for j in range(len(ids))] for row, A in enumerate(ids)}
+        self.strength = {A: np.nansum(np.abs(cov[row])) for row, A in enumerate(ids)}
+        self.strengthmap = np.full((self.dimX, self.dimY), np.nan)
+        for A in ids:
+            cells = np.asarray(self.V[A], dtype=np.int64)
+            self.strengthmap[cells[:, 0], cells[:, 1]] = self.strength[A]
+
+
+def significant_positive_mean(R, dof, significance):
+    """Mean of the entries of R that are >= 0 and whose one-sided p-value (Student t, ``dof`` degrees of freedom,
+    t = r sqrt(dof / (1 - r^2))) is below ``significance``.  NaN entries (the diagonal) never qualify."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        positive = R[R >= 0]
+        t_stat = positive * np.sqrt(dof / (1 - positive ** 2))
+    significant = stats.t.sf(t_stat, dof) < significance
+    return np.mean(positive[significant])
 
 
 def networks(dataset, latlon=False, area_key="psar", lat_key="lat", significance=0.01):

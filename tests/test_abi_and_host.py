@@ -255,3 +255,69 @@ def test_sigma_eigh_matches_expm_on_golden_laplacians():
             S = eig.sigma(1e9)                           # extreme l: still a symmetric stochastic matrix (M has zero row sums)
             assert np.allclose(S, S.T) and np.allclose(S.sum(axis=1), 1.0, atol=1e-6)
     assert checked >= 10
+
+
+def test_small_batch_factored_covariance_reproduces_expm():
+    """smallbatch.SmallBatch host logic (no GPU): the factored form staged for the device, A diag(w) A^T, equals
+    X expm(l M) X^T (north/June1st.py:264-265) in both modes -- eigh of M (weights exp(l lam)) and eigh of the Pade
+    Sigma~ (weights = its eigenvalues) -- and the test rows give k*, k**."""
+    from scipy.linalg import expm
+    from seaiceextentforecasting_amd.smallbatch import SmallBatch
+    from seaiceextentforecasting_amd.features import laplacian_M
+
+    class FakeEngine:
+        kernel, dtype = "netdiffusion", "f64"
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((30, 12)); y = rng.standard_normal(30); Xs = rng.standard_normal((2, 12))
+    M = laplacian_M(X)
+    sb = SmallBatch(FakeEngine())
+    ds = sb.add_dataset(X, y, Xs, M)
+    for ell in (1e-3, 0.05, 2.0):
+        Sig = expm(ell * M)
+        for mode in ("eigh", "pade"):
+            sb.add_fit(ds, ell, 0.1, expm=mode)
+            A, yy, lam, lam_mode = sb._sets[sb._fits[-1][0]]
+            w = np.exp(ell * lam) if lam_mode == 0 else np.maximum(lam, 0.0)
+            XX = np.vstack([X, Xs])
+            full = (A * w) @ A.T
+            want = XX @ Sig @ XX.T
+            assert np.max(np.abs(full - want)) <= 1e-12 * np.max(np.abs(want)), (ell, mode)
+            assert A.shape == (32, 12) and np.array_equal(yy, y)
+    assert len(sb._sets) == 1 + 3            # one shared eigh set + one Pade set per l
+    with pytest.raises(ValueError):
+        sb.add_dataset(np.zeros((200, 3)), np.zeros(200))
+    with pytest.raises(ValueError):
+        sb.add_fit(ds, -1.0, 0.1)
+
+
+def test_bench_refuses_to_run_a_multi_gpu_job_on_one_process():
+    """`--gpus N` must never silently measure one GPU.  Without a GPU the launcher exits with a message; with
+    a torchrun environment that disagrees with --gpus it exits too."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=200, env=env)
+    assert p.returncode != 0 and ("needs a GPU" in p.stderr or "GPU(s) visible" in p.stderr), p.stderr[-500:]
+    env["WORLD_SIZE"] = "4"; env["RANK"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=200, env=env)
+    assert p.returncode != 0 and "WORLD_SIZE=4" in p.stderr, p.stderr[-500:]
+
+
+def test_bench_grid_and_strong_scaling_bookkeeping():
+    """bench.py's step -> grid point map covers the SURVEY 8(d) ranges, and the strong-scaling deal covers every fit once."""
+    sys.path.insert(0, ROOT)
+    import bench
+    ells, sns = bench.grid_axes(8, "full")
+    assert len(ells) == 20 and len(sns) == 20 and np.isclose(ells[0], np.sqrt(8) * 0.1) and np.isclose(ells[-1], np.sqrt(8) * 10)
+    assert np.isclose(sns[0], 1e-3) and np.isclose(sns[-1], 10.0)
+    pts = {bench.grid_point(i, 8, "smoke") for i in range(16)}
+    assert len(pts) == 16 and bench.grid_point(16, 8, "smoke") == bench.grid_point(0, 8, "smoke")
+    G, years, steps = 40, 40, 3
+    for world in (1, 2, 4, 8):
+        seen = []
+        for rank in range(world):
+            mine = np.arange(steps * G)[rank::world]
+            yr = mine % years
+            period = len(np.unique(yr))
+            assert np.array_equal(yr, np.tile(yr[:period], len(yr) // period + 1)[:len(yr)])     # what run_batch's (first + i) % sets assumes
+            seen += list(mine)
+        assert sorted(seen) == list(range(steps * G))

@@ -2,7 +2,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from seaiceextentforecasting_amd import _lib as L
-lib = L.load()
+lib = L.load(debug=True)   # libsigp_debug.so (make -C seaiceextentforecasting_amd/csrc debug)
 f = lib.sigp_debug_stream_concurrency
 f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, L._dp]
 h = C.c_void_p(); assert lib.sigp_create(C.byref(h), 0, 0) == 0
