@@ -77,8 +77,9 @@ def spawn_ranks(args):
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__)]
     env = dict(os.environ)
+    env["SIGP_BENCH_ARGV"] = json.dumps(sys.argv[1:])     # torchrun's own argparse would claim abbreviations such as --n / --d
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
@@ -103,7 +104,7 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=1, help="timed CPU repetitions at n=8192 (48 s each in the reference idiom; n=64 and n=4096 always run 1 warm-up + 3)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra records (other configs, MLII, reference-kernel grid)")
-    args = ap.parse_args()
+    args = ap.parse_args(json.loads(os.environ["SIGP_BENCH_ARGV"]) if len(sys.argv) == 1 and "SIGP_BENCH_ARGV" in os.environ else None)
 
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")

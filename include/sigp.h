@@ -40,7 +40,8 @@ enum { SIGP_MAT_K = 0, SIGP_MAT_L = 1 };
  * kbuild_kernel(+ride_build), potrf_diag_kernel, gemm_mfma_kernel<32,128> (panel solve),
  * gemm_mfma_kernel<64,64> (updates with few tiles), syrk128_kernel (inner + trailing updates), epilogue_kernel */
 enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_SMALL = 3,
-       SIGP_KC_SYRK128 = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_SMALL = 6 /* smallgp_kernel */, SIGP_KC_COUNT = 7 };
+       SIGP_KC_SYRK128 = 4, SIGP_KC_EPILOGUE = 5, SIGP_KC_SMALL = 6 /* smallgp_kernel */,
+       SIGP_KC_MLII = 7 /* triangular inversion + U U^T of sigp_nlml_grad */, SIGP_KC_COUNT = 8 };
 
 #define SIGP_MAX_RIDE 127 /* test points that can ride along one factorisation */
 
@@ -123,6 +124,21 @@ int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int
                       const double* lam_pool, const int64_t* lam_off);
 int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde,
                    double* out, double* mean, double* var, int64_t mstride);
+
+/* The caller that produces the GP's features: ComplexNetworks.Network.tau (ComplexNetworks.py:31-47) on the device.
+ * series [N][T] (row stride lds): the anomaly series of the N active grid cells.  Forms the N x N cell-to-cell correlation matrix
+ * (np.corrcoef: one fp64 MFMA product of the standardised rows, clipped to [-1, 1], NaN on the diagonal) into R [N][N] (row stride
+ * ldr; may be NULL) and returns the sum and the count of its entries with r >= 0 and r > r_crit -- the entries whose one-sided
+ * t-test p-value (dof = T - 2) is below the significance level, r_crit = t_c / sqrt(dof + t_c^2), t_c = t.isf(significance, dof).
+ * tau = sum / count. */
+int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, int64_t lds, double r_crit, double* R, int64_t ldr,
+                  double* sum_out, double* count_out);
+
+/* The step before the feature pipeline: detrend() of north/June1st.py:179-194 (one cut: cut_len = {T}) and of the retro
+ * scripts (north/retrospective_forecasts/June1st_retro.py:178-195: one detrended cube per cut-off year) in ONE launch.
+ * data [P][T] pixel-major anomaly series; cut c removes the least-squares line (scipy.stats.linregress semantics, NaN propagating)
+ * fitted to the first cut_len[c] steps.  dt_out: the cuts' [P][cut_len[c]] blocks back to back; trend_out [ncuts][P][2] = slope, intercept. */
+int sigp_detrend(sigp_handle* h, const double* data, int64_t P, int64_t T, int64_t ncuts, const int64_t* cut_len, double* dt_out, double* trend_out);
 
 /* named scalars of the last operation: "refine_residual" (fp32 engine: max|y - K~ alpha~| / max|y| after the last refinement
  * step), "matrix_bytes" (device bytes held by this handle's matrix / factor buffers). */

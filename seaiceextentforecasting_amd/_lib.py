@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libsigp.so")
 
 OK, NOT_SPD, BAD_ARG, HIP_ERROR = 0, 1, 2, 3
 KERNEL_IDS = {"netdiffusion": 0, "rbf": 1, "matern52": 2}
-KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_small": 3, "syrk128": 4, "epilogue": 5, "small": 6}
+KCLASS = {"kbuild": 0, "diag": 1, "trsm": 2, "update_small": 3, "syrk128": 4, "epilogue": 5, "small": 6, "mlii": 7}
 MAX_RIDE = 127
 
 _dp = C.POINTER(C.c_double)
@@ -43,6 +43,8 @@ SIGNATURES = {
     "sigp_small_upload": (C.c_int, [_h, _i64, _ip64, _ip64, _ip64, _ip32, _dp, _ip64, _dp, _ip64, _dp, _ip64]),
     "sigp_small_run": (C.c_int, [_h, _i64, _ip64, _dp, _dp, _dp, _dp, _dp, _i64]),
     "sigp_get_stat": (C.c_int, [_h, C.c_char_p, _dp]),
+    "sigp_detrend": (C.c_int, [_h, _dp, _i64, _i64, _i64, _ip64, _dp, _dp]),
+    "sigp_corr_tau": (C.c_int, [_h, _dp, _i64, _i64, _i64, C.c_double, _dp, _i64, _dp, _dp]),
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
     "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, C.POINTER(C.c_double), _dp]),
@@ -85,6 +87,13 @@ def load(debug=False):
         raise SigpError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                         "or `make -C seaiceextentforecasting_amd/csrc%s` (there is no CPU fallback)" % (path, " debug" if debug else ""))
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # must precede HIP runtime initialisation to take effect
+    try:
+        # PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  Whichever HIP runtime a process loads first serves
+        # every later user (same SONAME); torch cannot initialise on top of /opt/rocm's ("No HIP GPUs are available"),
+        # the other order works.  dist.DistributedGPR needs both in one process, so let torch's load first when it exists.
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol

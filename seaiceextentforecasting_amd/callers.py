@@ -28,15 +28,26 @@ def detrend_cube(data):
     return detrended, np.stack([slope, intercept], axis=2)
 
 
-def detrend(dataset, fmin=None, fmax=None):
+def detrend(dataset, fmin=None, fmax=None, engine=None):
     """In-place drop-in for the reference's ``detrend``: operational form ``detrend(dataset)`` sets
     ``dataset['dt'], dataset['trend']`` (north/June1st.py:179-194); retro form ``detrend(dataset, fmin, fmax)``
     sets ``dataset['dt_YYYY'], dataset['trend_YYYY']`` from the first YYYY-1979+1 years
-    (north/retrospective_forecasts/June1st_retro.py:178-195)."""
+    (north/retrospective_forecasts/June1st_retro.py:178-195).  ``engine``: a ``GPR`` handle -- every cut-off year is then
+    detrended on the GPU in one launch (``sigp_detrend``)."""
     if fmin is None:
-        dataset["dt"], dataset["trend"] = detrend_cube(dataset["data"])
+        if engine is not None:
+            (dt,), (tr,) = engine.detrend_cuts(dataset["data"], [np.asarray(dataset["data"]).shape[2]])
+            dataset["dt"], dataset["trend"] = dt, tr
+        else:
+            dataset["dt"], dataset["trend"] = detrend_cube(dataset["data"])
         return dataset
-    for year in range(fmin, fmax + 1):
+    years = list(range(fmin, fmax + 1))
+    if engine is not None:
+        dts, trs = engine.detrend_cuts(dataset["data"], [year - 1979 + 1 for year in years])
+        for year, dt, tr in zip(years, dts, trs):
+            dataset["dt_%d" % year], dataset["trend_%d" % year] = dt, tr
+        return dataset
+    for year in years:
         n = year - 1979 + 1
         dataset["dt_%d" % year], dataset["trend_%d" % year] = detrend_cube(dataset["data"][:, :, :n])
     return dataset

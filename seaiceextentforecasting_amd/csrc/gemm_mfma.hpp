@@ -74,6 +74,10 @@ struct GemmArgsT {
   unsigned long long* stamp;   // debug: per-workgroup {s_memtime, s_memrealtime} deltas over the kernel body (nullptr = off)
   int dbg;                     // timing ablations (debug only): 1 no global loads in loop, 2 no LDS stores, 4 no barrier
   int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD
+  int ntile;                   // persistent launches (grid.y == 1, grid.x = resident workgroups): tiles per batch member; workgroup w
+                               // then walks the flattened (member, tile) list w, w + grid.x, ... (member-major).  0 = one tile per workgroup.
+  int ktri;                    // triangular operands: 1 = k starts at TM*bi (rows of A -- and of B in a lower SYRK -- are zero left of
+                               // their diagonal block: upper-triangular factors), 2 = k stops after TN*(bj+1) (BT image upper-triangular)
 };
 typedef GemmArgsT<double> GemmArgs;
 
@@ -227,7 +231,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
     }                                                                                          \
   }
 
-  const int nst = g.K / KTe;
+  int Kspan = g.K;
+  if (g.ktri == 1) { const int ks = bi * TM; Ag += ks; Bg += BT ? (long)ks * g.ldb : (long)ks; Kspan -= ks; }
+  if (g.ktri == 2) Kspan = min(Kspan, (bj + 1) * TN);
+  const int nst = Kspan / KTe;
   const int dbg = g.dbg & DBG_MASK;
   SIGP_GLOAD(0);
   SIGP_SSTORE(0);

@@ -216,7 +216,6 @@ __global__ void copy_block_kernel(const double* __restrict__ src, long lds, doub
   dst[(long)r * ldd + c] = src[(long)r * lds + c];
 }
 
-// identity into a [n_pad][n_pad] buffer
 // panel_mode 1: diagonal blocks of the Mt workspace = the inverse diagonal blocks of the panel (grid: block j, member)
 template <typename T>
 __global__ void mt_diag_kernel(const T* __restrict__ dinv, long dinvStride, T* __restrict__ Mt, long ldm, long mtStride) {
@@ -226,27 +225,36 @@ __global__ void mt_diag_kernel(const T* __restrict__ dinv, long dinvStride, T* _
   for (int e = threadIdx.x; e < 128 * 128; e += blockDim.x) dst[(long)(e >> 7) * ldm + (e & 127)] = src[e];
 }
 
-__global__ void set_identity_kernel(double* __restrict__ U, long ld, int n_pad) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)n_pad * n_pad) return;
-  const int r = (int)(idx / n_pad), c = (int)(idx % n_pad);
-  U[(long)r * ld + c] = (r == c) ? 1.0 : 0.0;
+// U[b][b] = dinv[b]^T for every 128-block b of the diagonal (one workgroup per block, through LDS so that both sides are
+// coalesced): the leaves of the recursive triangular inversion in sigp_nlml_grad.
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(const T* __restrict__ dinv, T* __restrict__ U, long ld) {
+  __shared__ T tile[32][33];
+  const T* src = dinv + (long)blockIdx.x * 128 * 128;
+  T* dst = U + (long)blockIdx.x * 128 * (ld + 1);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  for (int bi = 0; bi < 4; ++bi)
+    for (int bj = 0; bj < 4; ++bj) {
+      __syncthreads();
+      for (int r = ty; r < 32; r += 8) tile[r][tx] = src[(long)(bi * 32 + r) * 128 + bj * 32 + tx];
+      __syncthreads();
+      for (int r = ty; r < 32; r += 8) dst[(long)(bj * 32 + r) * ld + bi * 32 + tx] = tile[tx][r];
+    }
 }
 
-// K13/K14 reductions (north/June1st.py:251-252).  Kneg = -K~^-1 (lower triangle valid), D = a symmetric
+// K13/K14 reductions (north/June1st.py:251-252).  Kinv = K~^-1 (lower triangle valid), D = a symmetric
 // derivative matrix (full), a = A~ (K~^-1 y).  One block per row i < n:
-//   part[4i+0] = sum_j K~^-1_ij D_ij  (row i of the full symmetric product, from the lower triangle)
+//   part[4i+0] = Kinv_ii D_ii + 2 sum_{j<i} Kinv_ij D_ij   (row i's share of tr(K~^-1 D), lower triangle only)
 //   part[4i+1] = a_i * sum_j D_ij a_j
 //   part[4i+2] = K~^-1_ii              part[4i+3] = a_i^2
-__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kneg, const double* __restrict__ D,
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restrict__ Kinv, const double* __restrict__ D,
                                                           const double* __restrict__ a, long ld, int n, double* __restrict__ part) {
   __shared__ double sh[4];
   const int i = blockIdx.x;
   double t = 0.0, q = 0.0;
   for (int j = threadIdx.x; j < n; j += 256) {
     const double dij = D[(long)i * ld + j];
-    const double kij = (j <= i) ? -Kneg[(long)i * ld + j] : -Kneg[(long)j * ld + i];
-    t += kij * dij;
+    if (j <= i) t += (j < i ? 2.0 : 1.0) * Kinv[(long)i * ld + j] * dij;
     q += dij * a[j];
   }
   t = block_reduce_sum(t, sh);
@@ -254,9 +262,193 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
   if (threadIdx.x == 0) {
     part[4 * i + 0] = t;
     part[4 * i + 1] = a[i] * q;
-    part[4 * i + 2] = -Kneg[(long)i * ld + i];
+    part[4 * i + 2] = Kinv[(long)i * ld + i];
     part[4 * i + 3] = a[i] * a[i];
   }
+}
+
+// ---- block triangular solves with a handful of right-hand sides -------------------------------------------------------
+// (fp32 engine: x = L^-T L^-1 r of every refinement step, north/June1st.py:266 in preconditioner form.)  The factor is cut
+// into big column blocks of TS_BS whose diagonal blocks carry explicit inverses (trtri_levels with span = TS_BS/128), so a
+// solve is, per big block, ONE skinny product with the inverse diagonal block and ONE skinny update of everything that
+// remains -- 2 launches per 2048 columns, each streaming its part of L exactly once at HBM speed -- instead of two tile-GEMM
+// launches per 128 columns that move 128-row tiles for <= 4 useful rows.
+constexpr int TS_BS = 2048;
+constexpr int TS_RHS = 4;
+
+template <typename T> struct Vec16;
+template <> struct Vec16<float> { typedef f4 type; static constexpr int N = 4; };
+template <> struct Vec16<double> { typedef d2 type; static constexpr int N = 2; };
+
+// "row-dot":  Zout[r][j] (-)= sum_k Zin[r][k] * Mx[j*ld + k]   for the matrix rows j < nrows, one WAVE per row (the row is
+// contiguous in k: 16-byte loads, 1 KiB per wave-instruction).  kmode 0: k in [0, K);  1: k in [0, j] (rows of a lower-
+// triangular block);  2: k in [j, K) (rows of an upper-triangular block).  Elements outside the range are SELECTED away,
+// never multiplied (the other triangle of an inverse block is uninitialised memory).
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Mx, long ld, int nrows, int K, int kmode,
+                                                     const T* __restrict__ Zin, long ldzin, T* __restrict__ Zout, long ldzout,
+                                                     int nrhs, int sub) {
+  typedef typename Vec16<T>::type V;
+  constexpr int NV = Vec16<T>::N;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= nrows) return;
+  const int klo = kmode == 2 ? j : 0, khi = kmode == 1 ? j + 1 : K;       // [klo, khi)
+  const T* row = Mx + (long)j * ld;
+  T acc[TS_RHS];
+#pragma unroll
+  for (int r = 0; r < TS_RHS; ++r) acc[r] = (T)0;
+  const int step = 64 * NV;
+  for (int k0 = (klo / step) * step; k0 < khi; k0 += step) {
+    const int k = k0 + lane * NV;
+    if (k >= khi || k + NV <= klo) continue;
+    const V m = *(const V*)(row + k);
+#pragma unroll
+    for (int r = 0; r < TS_RHS; ++r) {
+      if (r < nrhs) {
+        const V z = *(const V*)(Zin + (long)r * ldzin + k);
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          const bool in = (k + e >= klo) && (k + e < khi);
+          acc[r] += in ? m[e] * z[e] : (T)0;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TS_RHS; ++r) {
+    T v = acc[r];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0 && r < nrhs) {
+      T* o = Zout + (long)r * ldzout + j;
+      *o = sub ? *o - v : v;
+    }
+  }
+}
+
+// "column-dot":  Zout[r][j] -= sum_{k < K} Zin[r][k] * Mx[k*ld + j]   for the columns j < ncols (the rows of Mx are
+// contiguous in j).  A workgroup owns 16 x (16 B) consecutive columns and splits k over its 16 thread rows; the 16 partial
+// sums meet in LDS in a fixed order (deterministic).
+template <typename T>
+__global__ __launch_bounds__(256) void coldot_kernel(const T* __restrict__ Mx, long ld, int ncols, int K,
+                                                     const T* __restrict__ Zin, long ldzin, T* __restrict__ Zout, long ldzout, int nrhs) {
+  typedef typename Vec16<T>::type V;
+  constexpr int NV = Vec16<T>::N;
+  constexpr int CW = 16 * NV;                                 // columns per workgroup
+  __shared__ T part[16][TS_RHS][CW + 1];
+  const int cl = threadIdx.x & 15, kg = threadIdx.x >> 4;
+  const int j = blockIdx.x * CW + cl * NV;
+  T acc[TS_RHS][NV];
+#pragma unroll
+  for (int r = 0; r < TS_RHS; ++r)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) acc[r][e] = (T)0;
+  if (j < ncols) {
+    const int kper = (K + 15) / 16;
+    const int k1 = min(K, (kg + 1) * kper);
+    for (int k = kg * kper; k < k1; ++k) {
+      const V m = *(const V*)(Mx + (long)k * ld + j);
+#pragma unroll
+      for (int r = 0; r < TS_RHS; ++r) {
+        if (r < nrhs) {
+          const T z = Zin[(long)r * ldzin + k];
+#pragma unroll
+          for (int e = 0; e < NV; ++e) acc[r][e] = fma(z, m[e], acc[r][e]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < TS_RHS; ++r)
+#pragma unroll
+    for (int e = 0; e < NV; ++e) part[kg][r][cl * NV + e] = acc[r][e];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < nrhs * CW; idx += 256) {
+    const int r = idx / CW, c = idx % CW;
+    const int jc = blockIdx.x * CW + c;
+    if (jc >= ncols) continue;
+    T v = (T)0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v += part[g][r][c];
+    Zout[(long)r * ldzout + jc] -= v;
+  }
+}
+
+// dst big diagonal block b = (src big diagonal block b)^T, blocks of `bs` (last one `n - b*bs`) on the diagonal of [n][ld]
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_diag_blocks_kernel(const T* __restrict__ src, T* __restrict__ dst, long ld, int n, int bs) {
+  __shared__ T tile[32][33];
+  const int b = blockIdx.z, sz = min(bs, n - b * bs);
+  const int ti = blockIdx.y * 32, tj = blockIdx.x * 32;
+  if (ti >= sz || tj >= sz) return;
+  const long o = (long)b * bs * (ld + 1);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8) tile[r][tx] = src[o + (long)(ti + r) * ld + tj + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) dst[o + (long)(tj + r) * ld + ti + tx] = tile[tx][r];
+}
+
+// ---- ComplexNetworks tau() on the device (behaviour of ComplexNetworks.py:31-47) ---------------------------
+// Row standardisation  z_i = (x_i - mean_i) / ||x_i - mean_i||  so that the correlation matrix is the plain product Z Z^T
+// (one MFMA GEMM).  Z is [n_pad][k_pad], zero padded.  A series with a NaN or zero variance gives a NaN row, as np.corrcoef does.
+__global__ void corr_standardise_kernel(const double* __restrict__ X, long ldx, int n, int t, double* __restrict__ Z, int n_pad, int k_pad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad) return;
+  double* z = Z + (long)i * k_pad;
+  if (i >= n) { for (int k = 0; k < k_pad; ++k) z[k] = 0.0; return; }
+  const double* x = X + (long)i * ldx;
+  double m = 0.0;
+  for (int k = 0; k < t; ++k) m += x[k];
+  m /= (double)t;
+  double ss = 0.0;
+  for (int k = 0; k < t; ++k) { const double c = x[k] - m; ss = fma(c, c, ss); }
+  const double inv = 1.0 / sqrt(ss);
+  for (int k = 0; k < k_pad; ++k) z[k] = k < t ? (x[k] - m) * inv : 0.0;
+}
+
+// In place on R [n][ld]: clip to [-1, 1] (as np.corrcoef), NaN on the diagonal (a cell is not its own neighbour), and the
+// fused threshold reduction: per block, the sum and the count of the off-diagonal entries with r >= 0 and r > r_crit
+// (<=> one-sided t-test p-value below the significance level, t = r sqrt(dof / (1 - r^2)) being monotone in r).
+__global__ __launch_bounds__(256) void corr_threshold_kernel(double* __restrict__ R, long ld, int n, double r_crit, double* __restrict__ part) {
+  __shared__ double sh[4];
+  const int i = blockIdx.x;
+  double s = 0.0, c = 0.0;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    double r = R[(long)i * ld + j];
+    r = r > 1.0 ? 1.0 : (r < -1.0 ? -1.0 : r);        // NaN passes through both comparisons
+    if (j == i) r = __builtin_nan("");
+    R[(long)i * ld + j] = r;
+    if (r >= 0.0 && r > r_crit) { s += r; c += 1.0; }
+  }
+  s = block_reduce_sum(s, sh);
+  c = block_reduce_sum(c, sh);
+  if (threadIdx.x == 0) { part[2 * i] = s; part[2 * i + 1] = c; }
+}
+
+// ---- per-pixel linear detrending, every cut-off year in one launch (behaviour of north/June1st.py:179-194 and
+// north/retrospective_forecasts/June1st_retro.py:178-195: scipy.stats.linregress per pixel in a Python double loop) --------
+// data [P][T]; cut c uses the first ncut[c] time steps.  dt_out: cut c's detrended series at dt_off[c] + p*ncut[c]; trend_out
+// [ncuts][P][2] = slope, intercept.  One thread per (pixel, cut).  A pixel with any NaN inside the window comes out all-NaN
+// (linregress propagates it) -- plain IEEE arithmetic does the same.
+__global__ void detrend_kernel(const double* __restrict__ data, int P, int T, const int* __restrict__ ncut, const long* __restrict__ dt_off,
+                               int ncuts, double* __restrict__ dt_out, double* __restrict__ trend_out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x, c = blockIdx.y;
+  if (p >= P || c >= ncuts) return;
+  const int n = ncut[c];
+  const double* y = data + (long)p * T;
+  const double tm = 0.5 * (double)(n - 1);
+  double ym = 0.0;
+  for (int k = 0; k < n; ++k) ym += y[k];
+  ym /= (double)n;
+  double sxx = 0.0, sxy = 0.0;
+  for (int k = 0; k < n; ++k) { const double dt = (double)k - tm; sxx += dt * dt; sxy += dt * (y[k] - ym); }
+  const double slope = (sxy / (double)n) / (sxx / (double)n);
+  const double icpt = ym - slope * tm;
+  double* o = dt_out + dt_off[c] + (long)p * n;
+  for (int k = 0; k < n; ++k) o[k] = y[k] - (slope * (double)k + icpt);
+  trend_out[((long)c * P + p) * 2] = slope;
+  trend_out[((long)c * P + p) * 2 + 1] = icpt;
 }
 
 // ---- fp32 factor + fp64 iterative refinement (BASELINE configs[4]) -----------------------------------

@@ -75,6 +75,9 @@ struct sigp_handle {
   double* gT = nullptr; long cap_gT = 0;      // separate from Sig / T, which sigp_predict reads after a fit
   // fp32 engine (dtype == SIGP_F32): fp32 factor + fp64 iterative refinement (BASELINE configs[4])
   float* fmat = nullptr; float* fdinv = nullptr; float* fZ = nullptr; long cap_f_npad = 0;
+  float* fU = nullptr; float* fV = nullptr;  // [n_pad][n_pad] each: inverse-transposes of the factor's 2048-column diagonal blocks (fU, upper) and their
+                                             // transposes (fV, lower) for the block triangular solves of the refinement; only the diagonal big blocks are used
+  float* fXw = nullptr;                      // [4][n_pad] second working row set of those solves
   double* xq = nullptr;      // [4][n_pad] refined solutions: row 0 alpha~ = K~^-1 y, rows 1..m  w_j = K~^-1 k~*_j
   double* rq = nullptr;      // [4][n_pad] fp64 residuals
   double* fpart = nullptr;   // partial sums of the final dots
@@ -118,6 +121,8 @@ struct sigp_handle {
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
+  int opt_update_wgs = 0;    // > 0: trailing updates with more tiles than this run as a persistent grid of this many workgroups (slots left free
+                             // for the panel stream's latency chain); 0: one workgroup per tile
   int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
   int opt_host_timing = 0;   // print host enqueue time per batch_run (debug)
   int opt_reserve_cus = 0;   // CUs masked out of the update streams (0: none -- the 84 KB diagonal kernel fits beside an update workgroup, and a CU-masked stream measured 6 % slower)
@@ -315,11 +320,21 @@ template <int TM, int TN, int WM, int WN, int MODE, bool BT>
 int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgs& g) { return launch_gemm_cfg<double, TM, TN, WM, WN, MODE, BT>(h, st, g); }
 
 template <typename T, bool SET>
-int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
+int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool may_persist = false) {
   const int nt = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, g.patch);
   if (nt <= 0) return SIGP_OK;
   static AttrOnce attr;
   HIPCHK(h, attr.set(h->device, (const void*)syrk128_kernel<T, SET>, SY_LDS_BYTES));
+  const long total = (long)nt * std::max(1, g.batch);
+  if (may_persist && h->opt_update_wgs > 0 && g.patch == 0 && total > h->opt_update_wgs) {
+    GemmArgsT<T> gp = g;
+    gp.ntile = nt;
+    static AttrOnce attr_p;
+    HIPCHK(h, attr_p.set(h->device, (const void*)syrk128_kernel<T, SET, true>, SY_LDS_BYTES));
+    hipLaunchKernelGGL((syrk128_kernel<T, SET, true>), dim3(h->opt_update_wgs, 1), dim3(256), SY_LDS_BYTES, st, gp);
+    HIPCHK(h, hipGetLastError());
+    return SIGP_OK;
+  }
   hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -341,7 +356,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
     if (h->opt_c_dma) g.dbg |= 128;
-    return launch_syrk128_t<T, false>(h, st, g);
+    return launch_syrk128_t<T, false>(h, st, g, true);
   }
   if (nt >= h->opt_small_tiles) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
@@ -706,19 +721,62 @@ static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
   return solve_rows_backward_t<double>(h, s.s_upd, s.mat, s.dinv, Z, n_pad);
 }
 
+// U = L^-T (upper triangular, row-major, leading dimension ld) by recursive doubling from the inverse diagonal blocks
+// the factorisation left behind:  [L11 0; L21 L22]^-T = [U11  -U11 L21^T U22 ; 0  U22].  Level s joins every pair of
+// finished s-blocks (the last pair may be ragged) with two products -- P = U11 L21^T (LDS-DMA kernel, k starts at the
+// row's diagonal block) and U12 = -P U22 (k stops at the column's diagonal block) -- all pairs of a level in one launch
+// (grid.y = pair).  n^3/3 flops, every product MFMA work with K >= 128.  Levels stop below `span` (a power of two, in
+// 128-blocks): span >= T inverts the whole factor, span = S leaves the inverses of the aligned S-block diagonal blocks
+// (what the block triangular solves of the fp32 refinement use).  P is scratch of the same shape as U.
+// Blocks of U below its block diagonal are never written NOR read (the products skip them through GemmArgsT::ktri).
+template <typename Real>
+int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* dinvp, Real* U, Real* P, long ld, int T, int span) {
+  int rc;
+  hipLaunchKernelGGL(transpose_blocks_kernel<Real>, dim3(T), dim3(256), 0, st, dinvp, U, ld);
+  HIPCHK(h, hipGetLastError());
+  for (int sblk = 1; sblk < T && sblk < span; sblk *= 2) {
+    const int npairs_full = T / (2 * sblk);                           // pairs whose right block is a whole s-block
+    const int tail_left = npairs_full * 2 * sblk;                     // a ragged pair: left [tail_left, +s), right the rest
+    const int tail_r = T - tail_left - sblk;                          // > 0 when it exists
+    for (int pass = 0; pass < 2; ++pass) {
+      const int nb2 = pass == 0 ? npairs_full : (tail_r > 0 ? 1 : 0);
+      if (nb2 <= 0) continue;
+      const int b0 = pass == 0 ? 0 : tail_left;
+      const int rs = pass == 0 ? sblk : tail_r;                       // blocks in the right part
+      const long o = (long)b0 * NB * (ld + 1), pairStride = (long)2 * sblk * NB * (ld + 1);
+      GemmArgsT<Real> g1{};                                           // P = U11 L21^T
+      g1.A = U + o; g1.lda = ld; g1.sA = pairStride;
+      g1.B = Lm + o + (long)sblk * NB * ld; g1.ldb = ld; g1.sB = pairStride;
+      g1.C = P + o + (long)sblk * NB; g1.ldc = ld; g1.sC = pairStride;
+      g1.batch = nb2; g1.K = sblk * NB; g1.r0 = 0; g1.r1 = sblk; g1.c0 = 0; g1.c1 = rs; g1.lower = 0; g1.ktri = 1;
+      if ((rc = launch_syrk128_t<Real, true>(h, st, g1))) return rc;
+      GemmArgsT<Real> g2{};                                           // U12 = -P U22
+      g2.A = P + o + (long)sblk * NB; g2.lda = ld; g2.sA = pairStride;
+      g2.B = U + o + (long)sblk * NB * (ld + 1); g2.ldb = ld; g2.sB = pairStride;
+      g2.C = U + o + (long)sblk * NB; g2.ldc = ld; g2.sC = pairStride;
+      g2.batch = nb2; g2.K = rs * NB; g2.r0 = 0; g2.r1 = sblk; g2.c0 = 0; g2.c1 = rs; g2.lower = 0; g2.ktri = 2;
+      if ((rc = launch_gemm_cfg<Real, 128, 128, 2, 2, GEMM_SETNEG, true>(h, st, g2))) return rc;
+    }
+  }
+  return SIGP_OK;
+}
+
 // ---- fp32 engine: fp32 kernel matrix + Cholesky, fp64 iterative refinement of alpha~ and w_j -----------------
 // (BASELINE configs[4]; no reference counterpart -- the reference is fp64 NumPy.  Same outputs as the fp64 path:
 //  sigma_f, nlML, mean, var of north/June1st.py:267-277, 246.)
 int f32_reserve(sigp_handle* h, long n_pad) {
   if (h->cap_f_npad >= n_pad) return SIGP_OK;
   HIPCHK(h, hipDeviceSynchronize());
-  for (float** p : {&h->fmat, &h->fdinv, &h->fZ}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+  for (float** p : {&h->fmat, &h->fdinv, &h->fZ, &h->fU, &h->fV, &h->fXw}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
   for (double** p : {&h->xq, &h->rq, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
   h->cap_f_npad = 0;
   HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)(n_pad + RIDE) * n_pad * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->fdinv, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
   HIPCHK(h, hipMemset(h->fdinv, 0, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->fZ, (size_t)RIDE * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fU, (size_t)n_pad * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fV, (size_t)n_pad * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fXw, (size_t)TS_RHS * n_pad * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->xq, (size_t)4 * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->rq, (size_t)4 * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->fpart, (size_t)(n_pad / 256 + 1) * 8 * sizeof(double)));
@@ -765,6 +823,42 @@ int f32_build(sigp_handle* h, int kernel_id, double ell, double sn, const double
   return SIGP_OK;
 }
 
+// ---- block triangular solves of the fp32 refinement (kernels_misc.hpp: rowdot / coldot) ------------------------------
+// forward:  X = Z L^-T  (rows = right-hand sides; Z is consumed), backward:  Z = X L^-1 (X is consumed).  Right-looking over
+// the 2048-column big blocks: product with the explicit inverse of the diagonal block, then one update of everything left.
+int f32_block_forward(sigp_handle* h, hipStream_t st, long n_pad, int nrhs, float* Zw, float* Xout) {
+  const long ld = n_pad;
+  for (long c0 = 0; c0 < n_pad; c0 += TS_BS) {
+    const int kb = (int)std::min<long>(TS_BS, n_pad - c0);
+    const long rem = n_pad - (c0 + kb);
+    ProfScope ps(h, st, SIGP_KC_TRSM, 2.0 * nrhs * ((double)kb * kb / 2 + (double)rem * kb), 4.0 * ((double)kb * kb / 2 + (double)rem * kb));
+    hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((kb + 3) / 4)), dim3(256), 0, st, (const float*)(h->fV + c0 * (ld + 1)), ld, kb, kb, 1,
+                       (const float*)(Zw + c0), ld, Xout + c0, ld, nrhs, 0);
+    if (rem > 0)
+      hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((rem + 3) / 4)), dim3(256), 0, st, (const float*)(h->fmat + (c0 + kb) * ld + c0), ld, (int)rem, kb, 0,
+                         (const float*)(Xout + c0), ld, Zw + c0 + kb, ld, nrhs, 1);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SIGP_OK;
+}
+
+int f32_block_backward(sigp_handle* h, hipStream_t st, long n_pad, int nrhs, float* Xw, float* Zout) {
+  const long ld = n_pad;
+  const long nbig = (n_pad + TS_BS - 1) / TS_BS;
+  for (long b = nbig - 1; b >= 0; --b) {
+    const long c0 = b * TS_BS;
+    const int kb = (int)std::min<long>(TS_BS, n_pad - c0);
+    ProfScope ps(h, st, SIGP_KC_TRSM, 2.0 * nrhs * ((double)kb * kb / 2 + (double)c0 * kb), 4.0 * ((double)kb * kb / 2 + (double)c0 * kb));
+    hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((kb + 3) / 4)), dim3(256), 0, st, (const float*)(h->fU + c0 * (ld + 1)), ld, kb, kb, 2,
+                       (const float*)(Xw + c0), ld, Zout + c0, ld, nrhs, 0);
+    if (c0 > 0)
+      hipLaunchKernelGGL(coldot_kernel<float>, dim3((unsigned)(c0 / 64)), dim3(256), 0, st, (const float*)(h->fmat + c0 * ld), ld, (int)c0, kb,
+                         (const float*)(Zout + c0), ld, Xw, ld, nrhs);
+    HIPCHK(h, hipGetLastError());
+  }
+  return SIGP_OK;
+}
+
 int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
                long dp, long n_pad, long m, double* out, double* mean, double* var) {
   Slot& s = h->slots[0];
@@ -781,9 +875,19 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
   }
   HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  // inverse-transposes of the factor's 2048-column diagonal blocks (fU) and their transposes (fV; it is the scratch of the
+  // inversion first), for the block triangular solves below
+  {
+    const int T = (int)(n_pad / NB);
+    ProfScope ps(h, st, SIGP_KC_MLII, (double)n_pad * TS_BS * TS_BS / 3, 0.0);
+    if ((rc = trtri_levels<float>(h, st, h->fmat, h->fdinv, h->fU, h->fV, ld, T, TS_BS / NB))) return rc;
+    const int nbig = (int)((n_pad + TS_BS - 1) / TS_BS);
+    hipLaunchKernelGGL(transpose_diag_blocks_kernel<float>, dim3(TS_BS / 32, TS_BS / 32, (unsigned)nbig), dim3(256), 0, st, (const float*)h->fU, h->fV, ld, (int)n_pad, TS_BS);
+    HIPCHK(h, hipGetLastError());
+  }
   // x0 = L^-T (L^-1 b): the ride rows already hold L^-1 [y k*]; one backward block solve finishes them
-  HIPCHK(h, hipMemcpyAsync(h->fZ, h->fmat + n_pad * ld, (size_t)RIDE * n_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if ((rc = solve_rows_backward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->fXw, h->fmat + n_pad * ld, (size_t)nrhs * n_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if ((rc = f32_block_backward(h, st, n_pad, nrhs, h->fXw, h->fZ))) return rc;
   {
     const long tot = (long)nrhs * n_pad;
     hipLaunchKernelGGL((convert_rows_kernel<float, double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld,
@@ -798,13 +902,12 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
 #undef CALL_RES
     HIPCHK(h, hipGetLastError());
     if (it == h->opt_refine_iters) break;    // the last pass only measures the residual
-    HIPCHK(h, hipMemsetAsync(h->fZ, 0, (size_t)RIDE * n_pad * sizeof(float), st));
     const long tot = (long)nrhs * n_pad;
     hipLaunchKernelGGL((convert_rows_kernel<double, float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)h->rq, ld, h->fZ, ld,
                        nrhs, (int)n_pad, (int)n);
     HIPCHK(h, hipGetLastError());
-    if ((rc = solve_rows_forward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad, 1))) return rc;
-    if ((rc = solve_rows_backward_t<float>(h, st, h->fmat, h->fdinv, h->fZ, n_pad))) return rc;
+    if ((rc = f32_block_forward(h, st, n_pad, nrhs, h->fZ, h->fXw))) return rc;
+    if ((rc = f32_block_backward(h, st, n_pad, nrhs, h->fXw, h->fZ))) return rc;
     hipLaunchKernelGGL(accumulate_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld, nrhs,
                        (int)n_pad);
     HIPCHK(h, hipGetLastError());
@@ -891,6 +994,7 @@ int sigp_destroy(sigp_handle* h) {
   if (h->fmat) (void)hipFree(h->fmat);
   if (h->fdinv) (void)hipFree(h->fdinv);
   if (h->fZ) (void)hipFree(h->fZ);
+  for (float* p : {h->fU, h->fV, h->fXw}) if (p) (void)hipFree(p);
   for (double* p : bufs) if (p) (void)hipFree(p);
   delete h;
   return SIGP_OK;
@@ -931,6 +1035,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
   if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
   if (!strcmp(name, "reserve_cus")) {
@@ -1535,20 +1640,19 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   if ((rc = ensure(h, &h->gD, &h->cap_gD, n_pad * n_pad))) return rc;
   if ((rc = ensure(h, &h->gPart, &h->cap_gPart, 4 * n_pad))) return rc;
   if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, (long)RIDE * n_pad))) return rc;
-  // U = L~^-T: every 128-row chunk of the identity through the forward block solve, chunks in lockstep
+  // U = L~^-T (upper triangular, row-major in gU); P parks in gK
   {
-    const long tot = n_pad * n_pad;
-    hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->gU, ld, (int)n_pad);
-    HIPCHK(h, hipGetLastError());
-    if ((rc = solve_rows_forward(h, s, h->gU, n_pad, T))) return rc;
+    ProfScope ps(h, st, SIGP_KC_MLII, (double)n_pad * n_pad * n_pad / 3, 0.0);
+    if ((rc = trtri_levels<double>(h, st, s.mat, s.dinv, h->gU, h->gK, ld, T, T))) return rc;
   }
-  // -K~^-1 = -(U U^T) on the lower 128-tiles (the trailing-update kernel, K = n_pad)
+  // K~^-1 = U U^T on the lower 128-tiles (LDS-DMA kernel; rows of U are zero left of their diagonal block, so tile (i, j)
+  // sums k from 128 i: n^3/3 flops)
   {
-    HIPCHK(h, hipMemsetAsync(h->gK, 0, (size_t)n_pad * n_pad * sizeof(double), st));
+    ProfScope ps(h, st, SIGP_KC_MLII, (double)n_pad * n_pad * n_pad / 3, 0.0);
     GemmArgs g{};
     g.A = h->gU; g.lda = ld; g.B = h->gU; g.ldb = ld; g.C = h->gK; g.ldc = ld; g.K = (int)n_pad;
-    g.r0 = 0; g.r1 = T; g.c0 = 0; g.c1 = T; g.lower = 1;
-    if ((rc = launch_gemm_cfg<128, 128, 2, 2, GEMM_SUB, false>(h, st, g))) return rc;
+    g.r0 = 0; g.r1 = T; g.c0 = 0; g.c1 = T; g.lower = 1; g.ktri = 1;
+    if ((rc = launch_syrk128_t<double, true>(h, st, g))) return rc;
   }
   // A~ = L~^-T z by the backward block solve of the ride row
   HIPCHK(h, hipMemsetAsync(h->scratchZ, 0, (size_t)RIDE * n_pad * sizeof(double), st));
@@ -1675,6 +1779,76 @@ int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, cons
     HIPCHK(h, hipMemcpyAsync(mean, d_mean, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipMemcpyAsync(var, d_var, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
   }
+  HIPCHK(h, hipStreamSynchronize(st));
+  return SIGP_OK;
+}
+
+// ---- ComplexNetworks tau(): cell-to-cell correlation matrix + thresholded mean (ComplexNetworks.py:31-47) ------------
+int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, int64_t lds, double r_crit, double* R, int64_t ldr,
+                  double* sum_out, double* count_out) {
+  if (!h || !series || N < 2 || T < 3 || lds < T || !sum_out || !count_out || (R && ldr < N)) return fail(h, SIGP_BAD_ARG, "corr_tau: bad argument");
+  if (N > 46000) return fail(h, SIGP_BAD_ARG, "corr_tau: more than 46000 cells not supported (tile index range)");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->slots[0].s_upd;
+  const long n_pad = round_up(N, 64), k_pad = round_up(T, 16);
+  int rc;
+  // workspaces: raw series | Z | R | partial sums, carved out of the gradient buffers (n x n class)
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, N * lds))) return rc;
+  if ((rc = ensure(h, &h->gD, &h->cap_gD, n_pad * k_pad))) return rc;
+  if ((rc = ensure(h, &h->gK, &h->cap_gK, n_pad * n_pad))) return rc;
+  if ((rc = ensure(h, &h->gPart, &h->cap_gPart, 2 * n_pad))) return rc;
+  HIPCHK(h, hipMemcpyAsync(h->stage, series, (size_t)((N - 1) * lds + T) * sizeof(double), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(corr_standardise_kernel, dim3((unsigned)((n_pad + 127) / 128)), dim3(128), 0, st, (const double*)h->stage, (long)lds, (int)N, (int)T, h->gD, (int)n_pad,
+                     (int)k_pad);
+  HIPCHK(h, hipGetLastError());
+  {
+    GemmArgs g{};                                         // R = Z Z^T, all 64x64 tiles (area_level reads the full symmetric matrix)
+    g.A = h->gD; g.lda = k_pad; g.B = h->gD; g.ldb = k_pad; g.C = h->gK; g.ldc = n_pad; g.K = (int)k_pad;
+    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
+    ProfScope ps(h, st, SIGP_KC_KBUILD, 2.0 * N * N * T, 8.0 * N * N);
+    if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
+  }
+  hipLaunchKernelGGL(corr_threshold_kernel, dim3((unsigned)N), dim3(256), 0, st, h->gK, n_pad, (int)N, r_crit, h->gPart);
+  HIPCHK(h, hipGetLastError());
+  std::vector<double> part((size_t)2 * N);
+  HIPCHK(h, hipMemcpyAsync(part.data(), h->gPart, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+  if (R) HIPCHK(h, hipMemcpy2DAsync(R, (size_t)ldr * sizeof(double), h->gK, (size_t)n_pad * sizeof(double), (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  double s = 0, c = 0;
+  for (int64_t i = 0; i < N; ++i) { s += part[2 * i]; c += part[2 * i + 1]; }
+  *sum_out = s; *count_out = c;
+  return SIGP_OK;
+}
+
+// ---- detrend(): per-pixel least-squares line removal for every cut-off year in one launch --------------------------------
+int sigp_detrend(sigp_handle* h, const double* data, int64_t P, int64_t T, int64_t ncuts, const int64_t* cut_len, double* dt_out, double* trend_out) {
+  if (!h || !data || P < 1 || T < 2 || ncuts < 1 || !cut_len || !dt_out || !trend_out) return fail(h, SIGP_BAD_ARG, "detrend: bad argument");
+  std::vector<int> nc((size_t)ncuts);
+  std::vector<long> off((size_t)ncuts);
+  long tot = 0;
+  for (int64_t c = 0; c < ncuts; ++c) {
+    if (cut_len[c] < 2 || cut_len[c] > T) return fail(h, SIGP_BAD_ARG, "detrend: cut %ld uses %ld of %ld time steps", (long)c, (long)cut_len[c], (long)T);
+    nc[(size_t)c] = (int)cut_len[c]; off[(size_t)c] = tot; tot += P * cut_len[c];
+  }
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->slots[0].s_upd;
+  int rc;
+  const long hdr = round_up(ncuts * 2, 8);                       // cut lengths (int) + offsets (long), in doubles
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, P * T + hdr + 8))) return rc;
+  if ((rc = ensure(h, &h->gD, &h->cap_gD, tot + ncuts * P * 2))) return rc;
+  double* d_data = h->stage;
+  long* d_off = (long*)(h->stage + P * T);
+  int* d_nc = (int*)(d_off + ncuts);
+  double* d_dt = h->gD;
+  double* d_tr = h->gD + tot;
+  HIPCHK(h, hipMemcpyAsync(d_data, data, (size_t)(P * T) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_off, off.data(), (size_t)ncuts * sizeof(long), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_nc, nc.data(), (size_t)ncuts * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(detrend_kernel, dim3((unsigned)((P + 127) / 128), (unsigned)ncuts), dim3(128), 0, st, (const double*)d_data, (int)P, (int)T, (const int*)d_nc,
+                     (const long*)d_off, (int)ncuts, d_dt, d_tr);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(dt_out, d_dt, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(trend_out, d_tr, (size_t)(ncuts * P * 2) * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
   return SIGP_OK;
 }

@@ -180,7 +180,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   }
 }
 
-template <typename T, bool SET>
+template <typename T, bool SET, bool PERSIST = false>
 __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   constexpr int KTe = Num<T>::KT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -188,27 +188,43 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   T* Bs = As + 2 * SY_T * KTe;          // [2][128][KT]
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  int bi, bj;
-  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
-  const long bz = blockIdx.y;
-  const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
-  const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
-  T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
-  unsigned long long st_c0 = 0, st_r0 = 0;
   unsigned long long* const stamp = DBG_MASK ? g.stamp : nullptr;
-  if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
-  unsigned long long ph0 = 0, ph1 = 0;
-  syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, g.K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1);
-  if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
-    __builtin_amdgcn_s_waitcnt(0);
-    if (tid == 0) {
-      unsigned long long* o = stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
-      o[0] = ph0 - st_c0; o[1] = ph1 - ph0; o[2] = __builtin_amdgcn_s_memtime() - ph1;
+  // Persistent form (g.ntile > 0): the grid is a fixed number of resident workgroups, FEWER than the chip's 2-per-CU slots,
+  // each walking the flattened (member, tile) list with a stride of the grid size.  The slots left open are what the
+  // panel stream's latency-chain kernels (diagonal blocks, top-block solves) start in without waiting for an update
+  // workgroup to retire.  Tiles cost the same, so the static deal is balanced to within one tile.
+  const int total = PERSIST ? g.ntile * max(1, g.batch) : 1;
+  for (int t = PERSIST ? (int)blockIdx.x : 0; t < total; t += PERSIST ? (int)gridDim.x : 1) {
+    int bi, bj;
+    long bz;
+    if (PERSIST) {
+      bz = t / g.ntile;
+      if (!gemm_tile_coords(g, t - (int)bz * g.ntile, bi, bj)) continue;
+    } else {
+      bz = blockIdx.y;
+      if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
     }
-  }
-  if (stamp && tid == 0) {
-    stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
-    stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+    const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
+    const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
+    int K = g.K;
+    if (g.ktri == 1) { const int ks = bi * SY_T; Ag += ks; Bg += ks; K -= ks; }   // upper-triangular operand rows: nothing left of the diagonal block
+    T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
+    unsigned long long st_c0 = 0, st_r0 = 0;
+    if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+    unsigned long long ph0 = 0, ph1 = 0;
+    syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1);
+    if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
+      __builtin_amdgcn_s_waitcnt(0);
+      if (tid == 0) {
+        unsigned long long* o = stamp + 2 * ((size_t)gridDim.x * gridDim.y) + 3 * (blockIdx.y * gridDim.x + blockIdx.x);
+        o[0] = ph0 - st_c0; o[1] = ph1 - ph0; o[2] = __builtin_amdgcn_s_memtime() - ph1;
+      }
+    }
+    if (stamp && tid == 0) {
+      stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = __builtin_amdgcn_s_memtime() - st_c0;
+      stamp[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = ((__builtin_amdgcn_s_memrealtime() - st_r0) << 8) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 0xf);
+    }
+    if (PERSIST) __syncthreads();   // every wave is done with the LDS buffers before the next tile's first DMA lands in them
   }
 }
 

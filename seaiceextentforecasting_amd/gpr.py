@@ -432,6 +432,36 @@ class GPR:
             r = self.fit_batch(X, y, None, E.reshape(-1), S.reshape(-1), concurrency=concurrency, group=group)
         return r["nlml"].reshape(len(ells), len(sns))
 
+    # ---- the feature pipeline's correlation threshold on the device (networks.Network.tau(engine=gp)) --------------
+    def corr_tau(self, series, dof, significance):
+        """Cell-to-cell correlation matrix of ``series`` [N, T] and the mean of its significantly positive entries
+        (behaviour of ComplexNetworks.py:31-47): returns (R [N, N] with a NaN diagonal, tau)."""
+        from scipy import stats
+        series = L.f64(series, 2)
+        N, T = series.shape
+        t_c = float(stats.t.isf(significance, dof))
+        r_crit = t_c / np.sqrt(dof + t_c * t_c)
+        R = np.empty((N, N))
+        s, c = C.c_double(), C.c_double()
+        self._check(self._lib.sigp_corr_tau(self._h, L.ptr(series), N, T, T, r_crit, L.ptr(R), N, C.byref(s), C.byref(c)), "corr_tau")
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return R, np.float64(s.value) / np.float64(c.value)
+
+    def detrend_cuts(self, data, cut_lens):
+        """Per-pixel line removal of ``data`` [X, Y, T] over its first ``cut_lens[c]`` steps, every cut in one launch
+        (callers.detrend(engine=gp)).  Returns ([dt [X, Y, n_c] ...], [trend [X, Y, 2] ...])."""
+        data = L.f64(data, 3)
+        X, Y, T = data.shape
+        cuts = np.ascontiguousarray(cut_lens, dtype=np.int64)
+        dt = np.empty(int(X * Y * cuts.sum()))
+        tr = np.empty((len(cuts), X, Y, 2))
+        self._check(self._lib.sigp_detrend(self._h, L.ptr(data), X * Y, T, len(cuts), L.iptr(cuts), L.ptr(dt), L.ptr(tr)), "detrend")
+        outs, o = [], 0
+        for n in cuts:
+            outs.append(dt[o:o + X * Y * n].reshape(X, Y, int(n)))
+            o += X * Y * int(n)
+        return outs, [tr[c] for c in range(len(cuts))]
+
     # ---- measurement ---------------------------------------------------------------------------
     def profile(self, enable=True, classes=None):
         """Bracket kernel launches with HIP events (all classes, or only the named ones, e.g. ["syrk128"])."""
