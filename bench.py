@@ -340,9 +340,66 @@ def other_configs(local):
             fl = mlii_flops(n, 8)
             ml["n=%d" % n] = {"ms": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
                               "algorithmic_flops": fl}
+    rec["reference_kernel_grid"] = reference_kernel_grid(local)
     ml["note"] = "one MLII evaluation = fit (n^3/3) + L~^-T by recursive triangular inversion (n^3/3) + lower K~^-1 = U U^T (n^3/3) + O(n^2 d) derivative/reductions"
     rec["mlii"] = ml
     return rec
+
+
+def reference_kernel_grid(local):
+    """The reference's OWN kernel at the reference's OWN size: the retro loop's 3 regions x 40 years
+    (n = 6 .. 45 training years, N = 60 / 20 / 12 network areas) x the 20 x 20 grid of north/June1st.py:210-211 = 48 000 fits
+    in ONE launch (one workgroup per fit), beside the oracle's loop over a sample of the same fits on the host."""
+    import torch
+    from seaiceextentforecasting_amd import GPR, SmallBatch, LGRID, SGRID
+    rng = np.random.default_rng(20240010)
+    sets = []
+    for N in (60, 20, 12):
+        for t in range(40):
+            n = 6 + t
+            X = rng.standard_normal((n, N)) * (1.0 + 0.3 * rng.standard_normal(N))
+            y = X @ rng.standard_normal(N) / np.sqrt(N) + 0.5 * rng.standard_normal(n)
+            sets.append((X, y, rng.standard_normal((1, N))))
+    with GPR(kernel="netdiffusion", device=local) as gp:
+        t0 = time.perf_counter()
+        sb = SmallBatch(gp)
+        for X, y, Xs in sets:
+            ds = sb.add_dataset(X, y, Xs)
+            for e in LGRID:
+                for s_ in SGRID:
+                    sb.add_fit(ds, e, s_, expm="eigh")
+        sb.upload()
+        t_stage = time.perf_counter() - t0
+        r = sb.run()                                   # warm-up
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            r = sb.run()
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    F = len(r["nlml"])
+    flops = sum(400 * (n * n * N + n ** 3 / 3 + 4 * n * n) for (X, _, _) in sets for n, N in [X.shape])
+    out = {"fits": F, "ok_fits": int(np.sum(r["info"] == 0)), "ms_per_launch": 1e3 * dt, "fits_per_s": F / dt, "host_staging_s": t_stage,
+           "gflops": flops / dt / 1e9,
+           "note": "smallgp_kernel: K~ from the factored covariance + Cholesky + ride-along solves in LDS; latency/LDS-bound (orders <= 45), not an MFMA kernel; "
+                   "time includes the H2D copy of the fit list and the D2H copy of the results; host staging = one eigh of M per data set + packing"}
+    try:
+        from oracle import gp_oracle as O
+        sample = [sets[39], sets[79], sets[119]]        # the largest year of each region
+        t0 = time.perf_counter(); cnt = 0
+        for X, y, Xs in sample:
+            M = O.laplacian_M(X)
+            for e in LGRID[::4]:
+                for s_ in SGRID[::4]:
+                    try:
+                        O.fit_predict(X, y, Xs, e, s_, kind="netdiffusion", M=M, ref_idiom=True)
+                    except Exception:
+                        pass
+                    cnt += 1
+        tc = time.perf_counter() - t0
+        out["cpu_oracle_loop"] = {"fits_per_s": cnt / tc, "sample": "%d fits (3 data sets x 5 x 5 grid points), oracle ref_idiom=True (two expm + two Cholesky + gesv solves per fit, north/June1st.py:264-277)" % cnt}
+    except ImportError:
+        pass
+    return out
 
 
 def mlii_flops(n, d):

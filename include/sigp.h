@@ -162,6 +162,14 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
  * only updates the panels it owns; a factored panel is packed into a contiguous device buffer, broadcast,
  * and unpacked by the other ranks.  J, W, c0, c1 are in units of 128-column blocks.
  * Replaces the same np.linalg.cholesky call (north/June1st.py:265) as sigp_potrf.
+ * Transport: this ABI deliberately has NO sigp_dist_init(nranks, rank, nccl_id) -- the library never opens an RCCL communicator of
+ * its own.  One process per GPU already owns one (torch.distributed, backend "nccl" = RCCL over xGMI), and a second communicator
+ * per process would only duplicate rings and bootstrap; so the library exposes the panel as a contiguous DEVICE buffer
+ * (sigp_dist_panel_pack / _unpack) and stream-ordering hooks (sigp_dist_mark / _sync), and the caller moves that buffer with whatever
+ * collective it owns -- dist.DistributedGPR uses torch.distributed.broadcast(async_op=True); a C caller would hand the same pointer to
+ * ncclBroadcast.  sigp_dist_panel_pack returns only after the pack has completed on the library's private stream
+ * (hipStreamSynchronize) and the host side waits for the collective before sigp_dist_panel_unpack: both synchronisations are REQUIRED,
+ * they are what orders the library's non-blocking streams against the collective's stream.
  * Works for both engines: on an fp32 handle (BASELINE configs[4]) sigp_kernel_build builds the fp32 matrix, the panels
  * travel as fp32 (dev_buf holds floats) and sigp_dist_finish runs the fp64 iterative refinement on every rank. */
 int sigp_dist_begin(sigp_handle* h);                                   /* after sigp_kernel_build*: reset info  */
@@ -182,6 +190,26 @@ int sigp_dist_mark(sigp_handle* h);
 /* after the last panel: reductions + results, as sigp_fit_predict's out/mean/var; marks the handle fitted */
 int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var);
 int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_pad / 128                        */
+
+/* The same sharded fit with OWNER-ONLY storage (fp64): a rank allocates, builds and updates only the block columns of the panels it
+ * owns (panel q belongs to rank q % world; per-rank matrix bytes ~ 1/world), applies a received panel straight out of the receive
+ * buffer (no unpack), and the ride-row reductions come back as partial sums that the caller adds over the ranks (one all-reduce of
+ * 512 doubles -- the only other exchange besides the panel broadcast).  Replaces the same statements as above
+ * (north/June1st.py:265-277, :246).  After the fit the factor is spread over the ranks, so only the ride-along predictions exist.
+ *   set_option("owner_only", 1) before sigp_set_train keeps it from allocating the n x n slot matrix.
+ *   begin(W, world, rank) -> build(kernel_id, ell, sn~, Sigma|NULL, ldsigma) -> for p in panels: owner: factor(p, buf, &info); broadcast buf;
+ *   every rank: update(p, buf, q, slot) for its q > p -> reduce(res) -> all-reduce(res) -> results(res, info, out, mean, var).
+ * dev_buf holds sigp_dist_panel_elems(h, p*W, width_p) doubles; with two receive buffers in rotation call buffer_wait(slot) before
+ * receiving into a buffer whose previous panel may still be read by updates in flight (dist_async). */
+int sigp_dist_local_begin(sigp_handle* h, int64_t W, int64_t world, int64_t rank);
+int sigp_dist_local_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma);
+int64_t sigp_dist_local_panels(sigp_handle* h);
+int64_t sigp_dist_local_owner(sigp_handle* h, int64_t p);
+int sigp_dist_local_factor(sigp_handle* h, int64_t p, void* dev_buf, int64_t* info);
+int sigp_dist_local_update(sigp_handle* h, int64_t p, const void* dev_buf, int64_t q, int buf_slot);
+int sigp_dist_local_buffer_wait(sigp_handle* h, int buf_slot);
+int sigp_dist_local_reduce(sigp_handle* h, double* res);
+int sigp_dist_local_results(sigp_handle* h, const double* res, int64_t info, double* out, double* mean, double* var);
 
 /* measurement ---------------------------------------------------------------------------------- */
 /* enable=1: bracket every kernel launch with HIP events on the stream it is launched on and

@@ -58,6 +58,15 @@ SIGNATURES = {
     "sigp_dist_mark": (C.c_int, [_h]),
     "sigp_dist_finish": (C.c_int, [_h, _i64, _dp, _dp, _dp]),
     "sigp_num_blocks": (_i64, [_h]),
+    "sigp_dist_local_begin": (C.c_int, [_h, _i64, _i64, _i64]),
+    "sigp_dist_local_build": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, _dp, _i64]),
+    "sigp_dist_local_panels": (_i64, [_h]),
+    "sigp_dist_local_owner": (_i64, [_h, _i64]),
+    "sigp_dist_local_factor": (C.c_int, [_h, _i64, C.c_void_p, C.POINTER(_i64)]),
+    "sigp_dist_local_update": (C.c_int, [_h, _i64, C.c_void_p, _i64, C.c_int]),
+    "sigp_dist_local_buffer_wait": (C.c_int, [_h, C.c_int]),
+    "sigp_dist_local_reduce": (C.c_int, [_h, _dp]),
+    "sigp_dist_local_results": (C.c_int, [_h, _dp, _i64, _dp, _dp, _dp]),
     "sigp_profile": (C.c_int, [_h, C.c_int]),
     "sigp_profile_get": (C.c_int, [_h, C.c_int, _dp, C.POINTER(_i64), _dp, _dp]),
     "sigp_profile_reset": (C.c_int, [_h]),

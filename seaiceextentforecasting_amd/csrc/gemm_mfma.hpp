@@ -73,7 +73,8 @@ struct GemmArgsT {
   int lower;
   unsigned long long* stamp;   // debug: per-workgroup {s_memtime, s_memrealtime} deltas over the kernel body (nullptr = off)
   int dbg;                     // timing ablations (debug only): 1 no global loads in loop, 2 no LDS stores, 4 no barrier
-  int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD
+  int patch;                   // lower only: 0 = column-major walk, P>0 = PxP-tile patches per XCD (old, unbalanced), P<0 = XCD-chunked
+                               // walk in |P|x|P| patches over the flattened (member, tile) list (gemm_tile_coords_chunked; needs ntile)
   int ntile;                   // persistent launches (grid.y == 1, grid.x = resident workgroups): tiles per batch member; workgroup w
                                // then walks the flattened (member, tile) list w, w + grid.x, ... (member-major).  0 = one tile per workgroup.
   int ktri;                    // triangular operands: 1 = k starts at TM*bi (rows of A -- and of B in a lower SYRK -- are zero left of
@@ -146,6 +147,45 @@ __device__ inline bool gemm_tile_coords(const GemmArgsT<T>& g, int b, int& bi, i
   bj = g.c0 + pc * PATCH + (w % PATCH);
   bi = g.c0 + pr * PATCH + (w / PATCH);
   return bj < g.c1 && bi < g.r1 && bi >= bj && bi >= g.r0;
+}
+
+// XCD-chunked walk of a lower (trapezoid) tile space, all batch members flattened into one 1-D grid (g.patch < 0, g.ntile =
+// tiles per member).  Workgroup b runs on XCD b % 8 (round-robin dispatch) and the chip holds 512 of them (2 per CU), so
+//     b = round*512 + slot*8 + xcd   ->   u = (round*8 + xcd)*64 + slot
+// hands every XCD, per round, ONE chunk of 64 consecutive tiles of the patch-ordered tile list: an 8x8 patch of one member
+// (8 A row-blocks x 8 B row-blocks marching through K together, each K-slice fetched into that XCD's L2 once and used 8
+// times), instead of 64 tiles scattered over 60 row-blocks.  Every chunk but the last holds exactly 64 tiles, so the XCDs
+// stay balanced (the older `patch` walk padded half-empty diagonal patches with idle workgroups and lost 30 %).
+// Placement only affects speed, never results.
+template <typename T>
+__device__ inline bool gemm_tile_coords_chunked(const GemmArgsT<T>& g, unsigned b, int& bi, int& bj, long& bz) {
+  const unsigned round = b >> 9, slot = (b & 511u) >> 3, xcd = b & 7u;
+  const long u_all = ((long)round * 8 + xcd) * 64 + slot;
+  const int nb = g.batch > 1 ? g.batch : 1;
+  if (u_all >= (long)g.ntile * nb) return false;
+  bz = u_all / g.ntile;
+  int u = (int)(u_all - bz * g.ntile);
+  const int P = -g.patch;
+  const int pcols = (g.c1 - g.c0 + P - 1) / P, prows = (g.r1 - g.c0 + P - 1) / P;
+  for (int pc = 0; pc < pcols; ++pc) {
+    const int cj0 = g.c0 + pc * P, w = min(P, g.c1 - cj0);
+    for (int pr = pc; pr < prows; ++pr) {
+      const int ri0 = g.c0 + pr * P, hh = min(P, g.r1 - ri0);
+      if (hh <= 0) break;
+      if (pr > pc) {
+        const int cnt = w * hh;
+        if (u < cnt) { bi = ri0 + u / w; bj = cj0 + u % w; return true; }
+        u -= cnt;
+      } else {                                   // diagonal patch: row i of the patch has min(i + 1, w) tiles
+        for (int i = 0; i < hh; ++i) {
+          const int cnt = min(i + 1, w);
+          if (u < cnt) { bi = ri0 + i; bj = cj0 + u; return true; }
+          u -= cnt;
+        }
+      }
+    }
+  }
+  return false;
 }
 
 template <typename T, int TM, int TN, bool BT>

@@ -44,11 +44,14 @@ struct alignas(4 * sizeof(TO)) KbOut4 { TO v[4]; };
 template <typename TO>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
-                                                     const KParams* __restrict__ kps, int flags_in) {
-  const int flags = flags_in & (DBG_MASK | 1);
+                                                     const KParams* __restrict__ kps, int flags_in, int colblk0 = 0) {
+  const int flags = flags_in & (DBG_MASK | 1 | 8);
   const int full = flags & 1;      // flag bits 2 / 4: timing ablations (no covariance function / no store)
   int bi, bj;                      // 64-row tile, 128-column tile
-  if (full) {
+  if (flags & 8) {                 // "panel": the column blocks colblk0 .. colblk0 + gridDim.x of the lower triangle only (one rank's
+    bi = blockIdx.y; bj = colblk0 + blockIdx.x;   // share of a matrix sharded by block columns); Mat is the virtual origin of the
+    if (bi * KB_TM + KB_TM <= bj * KB_TN) return; // local storage, so global (row, column) indexing lands in it
+  } else if (full) {
     bi = blockIdx.y; bj = blockIdx.x;
   } else {                         // row-tile pair k = (2k, 2k+1) has column tiles 0..k
     const int u = blockIdx.x >> 1;
@@ -118,10 +121,11 @@ template <typename TO>
 __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restrict__ X, long strideX, const double* __restrict__ Xs,
                                                          long strideXs, const double* __restrict__ y, long stridey, int dp, int d,
                                                          int n, int n_pad, int m, int first_row, TO* __restrict__ Z,
-                                                         long strideZ, long ld, const KParams* __restrict__ kps, int compute_cov) {
-  const int i = blockIdx.x * 256 + threadIdx.x;   // column (training point)
-  const int r = blockIdx.y;                       // row of the ride block
-  if (i >= n_pad) return;
+                                                         long strideZ, long ld, const KParams* __restrict__ kps, int compute_cov,
+                                                         int i0 = 0, int icount = -1) {
+  const int i = i0 + blockIdx.x * 256 + threadIdx.x;   // column (training point); [i0, i0 + icount): one rank's block columns
+  const int r = blockIdx.y;                            // row of the ride block
+  if (i >= n_pad || (icount >= 0 && i >= i0 + icount)) return;
   const KParams kp = kps[blockIdx.z];
   X += kp.ds * strideX;
   Xs += kp.ds * strideXs;
@@ -145,9 +149,9 @@ __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restric
 }
 
 // after a GEMM-form build (reference kernel): add sn on the diagonal, identity on the padding
-__global__ void diag_fix_kernel(double* __restrict__ Mat, long ld, int n, int n_pad, double sn) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pad) return;
+__global__ void diag_fix_kernel(double* __restrict__ Mat, long ld, int n, int n_pad, double sn, int i0 = 0, int icount = -1) {
+  const int i = i0 + blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pad || (icount >= 0 && i >= i0 + icount)) return;
   if (i < n) Mat[(long)i * ld + i] += sn; else Mat[(long)i * ld + i] = 1.0;
 }
 
@@ -205,6 +209,16 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const TI* __restrict__ W,
     a = block_reduce_sum(a, sh);
     if (threadIdx.x == 0) res[256] = a;
   }
+}
+
+// sum_i log L_ii over the diagonal entries [i0, i0 + icount) n (i < n) of a matrix given by its virtual origin (one rank's
+// block columns of a factor sharded by columns); accumulates into *out (one block)
+__global__ __launch_bounds__(256) void logdiag_window_kernel(const double* __restrict__ Mat, long ld, int n, int i0, int icount, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double a = 0.0;
+  for (int i = i0 + threadIdx.x; i < i0 + icount && i < n; i += 256) a += log(Mat[(long)i * ld + i]);
+  a = block_reduce_sum(a, sh);
+  if (threadIdx.x == 0) *out += a;
 }
 
 // copy a [rows][cols] block (device -> device) with different strides

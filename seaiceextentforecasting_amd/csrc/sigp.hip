@@ -99,6 +99,18 @@ struct sigp_handle {
   SmallProb* sm_probs = nullptr; long cap_sm_probs = 0;
   double* sm_out = nullptr; long cap_sm_out = 0;   // [nprob][4 + 2*mstride]
   int sm_ch = 32, sm_mmax = 0; long sm_lds = 0;
+  // owner-only sharding of one large fit (sigp_dist_local_*): this rank's block columns only
+  struct DistLocal {
+    bool on = false;
+    int W = 0, world = 1, rank = 0, P = 0;     // panel width in 128-blocks, ranks, number of panels
+    std::vector<long> lcol;                    // per panel: first local column (elements), -1 = not this rank's
+    long ncol = 0;                             // local columns = row stride of mat
+    double* mat = nullptr; long cap = 0;       // [(n_pad + 128)][ncol]: own panels side by side, ride rows at the bottom
+    double* dinv = nullptr; long cap_dinv = 0; // [T][128][128] inverse diagonal blocks (own blocks filled)
+    hipEvent_t ev_buf[2] = {nullptr, nullptr}; // last update that read receive buffer k
+    bool ev_set[2] = {false, false};
+  } dl;
+  int opt_owner_only = 0;                      // sigp_set_train does not allocate the full n x n slot matrix
   // state
   int kernel_id = -1;
   double ell = 0, sn_tilde = 0;
@@ -121,6 +133,7 @@ struct sigp_handle {
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
+  int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
   int opt_update_wgs = 0;    // > 0: trailing updates with more tiles than this run as a persistent grid of this many workgroups (slots left free
                              // for the panel stream's latency chain); 0: one workgroup per tile
   int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
@@ -332,6 +345,13 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
     static AttrOnce attr_p;
     HIPCHK(h, attr_p.set(h->device, (const void*)syrk128_kernel<T, SET, true>, SY_LDS_BYTES));
     hipLaunchKernelGGL((syrk128_kernel<T, SET, true>), dim3(h->opt_update_wgs, 1), dim3(256), SY_LDS_BYTES, st, gp);
+    HIPCHK(h, hipGetLastError());
+    return SIGP_OK;
+  }
+  if (may_persist && h->opt_xcd_chunks > 0 && g.lower && g.patch == 0 && g.r0 <= g.c0 && total >= 512) {
+    GemmArgsT<T> gc = g;                       // XCD-chunked walk: one flat grid over (member, tile), padded to whole rounds of 512
+    gc.patch = -h->opt_xcd_chunks; gc.ntile = nt;
+    hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3((unsigned)round_up(total, 512), 1), dim3(256), SY_LDS_BYTES, st, gc);
     HIPCHK(h, hipGetLastError());
     return SIGP_OK;
   }
@@ -605,9 +625,10 @@ int dist_update(sigp_handle* h, Real* Mm, hipStream_t st, long n_pad, int kcol0,
   return gemm_sub_auto(h, st, g);
 }
 
+// Mm = (virtual) origin of the storage the panel's columns live in, row stride ld: the slot's square matrix (ld = n_pad) or one
+// rank's block columns (sigp_dist_local_*: ld = its column count, origin shifted so that GLOBAL column indices land in it)
 template <typename Real>
-int dist_panel(sigp_handle* h, Slot& s, Real* Mm, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
-  const long ld = n_pad;
+int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
   const int T = (int)(n_pad / NB), R = T + 1;
   if (Wp == 1) {
     const int c = J0;
@@ -624,10 +645,18 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, Real* dinvp, hipStream_t sp, l
     return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   }
   const int hw = Wp / 2;
-  int rc = dist_panel<Real>(h, s, Mm, dinvp, sp, n_pad, J0, hw);
+  int rc = dist_panel<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, hw);
   if (rc) return rc;
-  if ((rc = dist_update<Real>(h, Mm, sp, n_pad, J0, hw, J0 + hw, 0, Wp - hw))) return rc;
-  return dist_panel<Real>(h, s, Mm, dinvp, sp, n_pad, J0 + hw, Wp - hw);
+  {   // columns of the right half -= (left half)(left half)^T, rows from the right half's diagonal block down
+    const long o = (long)(J0 + hw) * NB;
+    GemmArgsT<Real> g{};
+    g.A = Mm + o * ld + (long)J0 * NB; g.lda = ld;
+    g.B = g.A; g.ldb = ld;
+    g.C = Mm + o * ld + o; g.ldc = ld;
+    g.batch = 1; g.K = hw * NB; g.r0 = 0; g.r1 = R - (J0 + hw); g.c0 = 0; g.c1 = Wp - hw; g.lower = 1;
+    if ((rc = gemm_sub_auto(h, sp, g))) return rc;
+  }
+  return dist_panel<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0 + hw, Wp - hw);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
@@ -989,6 +1018,9 @@ int sigp_destroy(sigp_handle* h) {
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
   double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
+  if (h->dl.mat) (void)hipFree(h->dl.mat);
+  if (h->dl.dinv) (void)hipFree(h->dl.dinv);
+  for (auto e : h->dl.ev_buf) if (e) (void)hipEventDestroy(e);
   if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
   if (h->sm_probs) (void)hipFree(h->sm_probs);
   if (h->fmat) (void)hipFree(h->fmat);
@@ -1030,11 +1062,13 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) { h->opt_syrk_v2 = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
   if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
@@ -1066,7 +1100,8 @@ int sigp_set_train(sigp_handle* h, const double* X, int64_t n, int64_t d, int64_
   if ((rc = ensure(h, &h->y, &h->cap_y, n_pad))) return rc;
   if ((rc = ensure(h, &h->Xs, &h->cap_Xs, (long)RIDE * dp))) return rc;
   if ((rc = ensure(h, &h->stage, &h->cap_stage, std::max<long>(n * ldx, n_pad)))) return rc;
-  if ((rc = slot_reserve(h, h->slots[0], h->dtype == SIGP_F64 ? n_pad : (long)NB, 1))) return rc;
+  if ((rc = slot_reserve(h, h->slots[0], (h->dtype == SIGP_F64 && !h->opt_owner_only) ? n_pad : (long)NB, 1))) return rc;
+  h->dl.on = false;
   hipStream_t st = h->slots[0].s_upd;
   HIPCHK(h, hipMemcpyAsync(h->stage, X, (size_t)((n - 1) * ldx + d) * sizeof(double), hipMemcpyHostToDevice, st));
   {
@@ -1134,11 +1169,13 @@ int sigp_kernel_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde
   return SIGP_OK;
 }
 
-static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde) {
-  // K~ = X Sigma~ X^T + sn I  (north/June1st.py:265);  ride rows = [y ; Xs Sigma~ X^T]
+// Reference kernel, GEMM form (north/June1st.py:264-265): stage Sigma~ and T = X Sigma~ (sigma_prepare), then emit the block
+// columns [cb0, cb1) of K~ = T X^T + sn I (lower 64-tiles) and of the ride rows [y ; Xs T^T] into storage given by its (virtual)
+// origin Cm with row stride ldc (sigma_emit): the slot's square matrix, or one rank's block columns (sigp_dist_local_build).
+static int sigma_prepare(sigp_handle* h, const double* Sigma, int64_t ldsigma) {
   Slot& s = h->slots[0];
   hipStream_t st = s.s_upd;
-  const long n = h->n, N = h->d, dp = h->dp, n_pad = h->n_pad, ld = n_pad;
+  const long n = h->n, N = h->d, dp = h->dp, n_pad = h->n_pad;
   int rc;
   if ((rc = ensure(h, &h->Sig, &h->cap_Sig, dp * dp))) return rc;
   if ((rc = ensure(h, &h->T, &h->cap_T, n_pad * dp))) return rc;
@@ -1160,30 +1197,63 @@ static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t l
     ProfScope ps(h, st, SIGP_KC_KBUILD, 2.0 * n * N * N, 8.0 * (2 * n * N + N * N));
     if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
   }
-  // K~ lower tiles = T X^T
-  {
+  // XsA = Xs shifted down by one row (ride row 0 is y)
+  HIPCHK(h, hipMemsetAsync(h->XsA, 0, (size_t)RIDE * dp * sizeof(double), st));
+  if (h->m > 0)
+    HIPCHK(h, hipMemcpyAsync(h->XsA + dp, h->Xs, (size_t)h->m * dp * sizeof(double), hipMemcpyDeviceToDevice, st));
+  s.kps_host[0] = h->kp;
+  return upload_kparams(h, s, 1);
+}
+
+static int sigma_emit(sigp_handle* h, double* Cm, long ldc, int cb0, int cb1, double sn_tilde) {
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long n = h->n, N = h->d, dp = h->dp, n_pad = h->n_pad;
+  int rc;
+  {   // K~ lower tiles = T X^T
     GemmArgs g{};
-    g.A = h->T; g.lda = dp; g.B = h->X; g.ldb = dp; g.C = s.mat; g.ldc = ld; g.K = (int)dp;
-    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 1;
+    g.A = h->T; g.lda = dp; g.B = h->X; g.ldb = dp; g.C = Cm; g.ldc = ldc; g.K = (int)dp;
+    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = cb0 * 2; g.c1 = cb1 * 2; g.lower = 1;
     ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * n * N, 4.0 * n * (n + 1) + 16.0 * n * N);
     if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
-    hipLaunchKernelGGL(diag_fix_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, st, s.mat, ld, (int)n, (int)n_pad, sn_tilde);
+    const int i0 = cb0 * NB, ic = (cb1 - cb0) * NB;
+    hipLaunchKernelGGL(diag_fix_kernel, dim3((unsigned)((ic + 255) / 256)), dim3(256), 0, st, Cm, ldc, (int)n, (int)n_pad, sn_tilde, i0, ic);
     HIPCHK(h, hipGetLastError());
   }
-  // ride rows: row 0 <- y, rows 1..m <- Xs T^T  (XsA = Xs shifted down by one row)
-  {
-    HIPCHK(h, hipMemsetAsync(h->XsA, 0, (size_t)RIDE * dp * sizeof(double), st));
-    if (h->m > 0)
-      HIPCHK(h, hipMemcpyAsync(h->XsA + dp, h->Xs, (size_t)h->m * dp * sizeof(double), hipMemcpyDeviceToDevice, st));
+  {   // ride rows: row 0 <- y, rows 1..m <- Xs T^T
     GemmArgs g{};
-    g.A = h->XsA; g.lda = dp; g.B = h->T; g.ldb = dp; g.C = s.mat + n_pad * ld; g.ldc = ld; g.K = (int)dp;
-    g.r0 = 0; g.r1 = RIDE / 64; g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
+    g.A = h->XsA; g.lda = dp; g.B = h->T; g.ldb = dp; g.C = Cm + n_pad * ldc; g.ldc = ldc; g.K = (int)dp;
+    g.r0 = 0; g.r1 = RIDE / 64; g.c0 = cb0 * 2; g.c1 = cb1 * 2; g.lower = 0;
     if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
-    s.kps_host[0] = h->kp;
-    if ((rc = upload_kparams(h, s, 1))) return rc;
-    hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((n_pad + 255) / 256), 1, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
-                       (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, s.mat + n_pad * ld, 0L, ld, s.kps, 0);
+    const int i0 = cb0 * NB, ic = (cb1 - cb0) * NB;
+    hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((ic + 255) / 256), 1, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
+                       (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, Cm + n_pad * ldc, 0L, ldc, s.kps, 0, i0, ic);
     HIPCHK(h, hipGetLastError());
+  }
+  return SIGP_OK;
+}
+
+static int build_from_sigma_async(sigp_handle* h, const double* Sigma, int64_t ldsigma, double sn_tilde) {
+  int rc = sigma_prepare(h, Sigma, ldsigma);
+  if (rc) return rc;
+  return sigma_emit(h, h->slots[0].mat, h->n_pad, 0, (int)(h->n_pad / NB), sn_tilde);
+}
+
+// k~** = xs Sigma~ xs^T for the ride-along test points, on the host (m x N x N flops)
+static int sigma_kss(sigp_handle* h, const double* Sigma, int64_t ldsigma) {
+  if (h->m <= 0) return SIGP_OK;
+  std::vector<double> xs((size_t)h->m * h->dp);
+  HIPCHK(h, hipMemcpyAsync(xs.data(), h->Xs, xs.size() * sizeof(double), hipMemcpyDeviceToHost, h->slots[0].s_upd));
+  HIPCHK(h, hipStreamSynchronize(h->slots[0].s_upd));
+  h->kss_unit.assign((size_t)h->m, 0.0);
+  for (long j = 0; j < h->m; ++j) {
+    double acc = 0.0;
+    for (long a = 0; a < h->d; ++a) {
+      double t = 0.0;
+      for (long b = 0; b < h->d; ++b) t += Sigma[a * ldsigma + b] * xs[j * h->dp + b];
+      acc += xs[j * h->dp + a] * t;
+    }
+    h->kss_unit[j] = acc;
   }
   return SIGP_OK;
 }
@@ -1196,24 +1266,9 @@ int sigp_kernel_build_from_sigma(sigp_handle* h, const double* Sigma, int64_t ld
   HIPCHK(h, hipSetDevice(h->device));
   h->kp = make_kparams(SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde, 0);
   h->kernel_id = SIGP_KERNEL_NETDIFFUSION; h->ell = 0; h->sn_tilde = sn_tilde;
-  // k~** = xs Sigma~ xs^T on the host (m x N x N flops, tiny): needs the host copies -> recompute from device Xs
   int rc = build_from_sigma_async(h, Sigma, ldsigma, sn_tilde);
   if (rc) return rc;
-  if (h->m > 0) {
-    std::vector<double> xs((size_t)h->m * h->dp);
-    HIPCHK(h, hipMemcpyAsync(xs.data(), h->Xs, xs.size() * sizeof(double), hipMemcpyDeviceToHost, h->slots[0].s_upd));
-    HIPCHK(h, hipStreamSynchronize(h->slots[0].s_upd));
-    h->kss_unit.assign((size_t)h->m, 0.0);
-    for (long j = 0; j < h->m; ++j) {
-      double acc = 0.0;
-      for (long a = 0; a < h->d; ++a) {
-        double t = 0.0;
-        for (long b = 0; b < h->d; ++b) t += Sigma[a * ldsigma + b] * xs[j * h->dp + b];
-        acc += xs[j * h->dp + a] * t;
-      }
-      h->kss_unit[j] = acc;
-    }
-  }
+  if ((rc = sigma_kss(h, Sigma, ldsigma))) return rc;
   rc = sync_slot(h, h->slots[0]);
   if (rc) return rc;
   h->built = true; h->factored = h->fitted = false;
@@ -1893,8 +1948,8 @@ int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info) 
   // mark; later update-stream work waits for the factor
   hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
   if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
-  int rc = h->dtype == SIGP_F64 ? dist_panel<double>(h, s, s.mat, s.dinv, sp, h->n_pad, (int)J, (int)W)
-                                : dist_panel<float>(h, s, h->fmat, h->fdinv, sp, h->n_pad, (int)J, (int)W);
+  int rc = h->dtype == SIGP_F64 ? dist_panel<double>(h, s, s.mat, h->n_pad, s.dinv, sp, h->n_pad, (int)J, (int)W)
+                                : dist_panel<float>(h, s, h->fmat, h->n_pad, h->fdinv, sp, h->n_pad, (int)J, (int)W);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
   if (h->opt_dist_async) {
@@ -1993,6 +2048,194 @@ int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, do
   return SIGP_OK;
 }
 
+// ---- one large fit sharded over GPUs, OWNER-ONLY storage: a rank allocates, builds and updates only the block columns of the
+// panels it owns; a received panel is used straight out of the receive buffer (no unpack), and the ride-row reductions are
+// partial sums the host all-reduces.  (sigp_dist_* above is the replicated form: every rank ends up with the whole factor.)
+static double* dl_origin(sigp_handle* h, int q) {      // virtual origin of panel q's columns: element (i, j) = origin[i * ncol + j], j global
+  return h->dl.mat + h->dl.lcol[(size_t)q] - (long)q * h->dl.W * NB;
+}
+static int dl_width(const sigp_handle* h, int q) { return (int)std::min<long>(h->dl.W, h->n_pad / NB - (long)q * h->dl.W); }
+
+int sigp_dist_local_begin(sigp_handle* h, int64_t W, int64_t world, int64_t rank) {
+  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_local_begin: call set_train first");
+  if (h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "dist_local_begin: fp64 engine only (the fp32 refinement needs the whole factor on every rank)");
+  if (W < 1 || W > 64 || world < 1 || rank < 0 || rank >= world) return fail(h, SIGP_BAD_ARG, "dist_local_begin: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  auto& dl = h->dl;
+  const long T = h->n_pad / NB;
+  dl.W = (int)W; dl.world = (int)world; dl.rank = (int)rank; dl.P = (int)((T + W - 1) / W);
+  dl.lcol.assign((size_t)dl.P, -1);
+  long ncol = 0;
+  for (int q = 0; q < dl.P; ++q)
+    if (q % dl.world == dl.rank) { dl.lcol[(size_t)q] = ncol; ncol += (long)dl_width(h, q) * NB; }
+  dl.ncol = std::max<long>(ncol, NB);
+  const long need = (h->n_pad + RIDE) * dl.ncol;
+  if (dl.cap < need) {
+    HIPCHK(h, hipDeviceSynchronize());
+    if (dl.mat) HIPCHK(h, hipFree(dl.mat));
+    dl.mat = nullptr; dl.cap = 0;
+    HIPCHK(h, hipMalloc((void**)&dl.mat, (size_t)need * sizeof(double)));
+    dl.cap = need;
+  }
+  if (dl.cap_dinv < T * NB * NB) {
+    if (dl.dinv) HIPCHK(h, hipFree(dl.dinv));
+    dl.dinv = nullptr; dl.cap_dinv = 0;
+    HIPCHK(h, hipMalloc((void**)&dl.dinv, (size_t)(T * NB * NB) * sizeof(double)));
+    dl.cap_dinv = T * NB * NB;
+  }
+  HIPCHK(h, hipMemset(dl.dinv, 0, (size_t)(T * NB * NB) * sizeof(double)));     // strictly-upper parts stay zero
+  for (int k = 0; k < 2; ++k) {
+    if (!dl.ev_buf[k]) HIPCHK(h, hipEventCreateWithFlags(&dl.ev_buf[k], hipEventDisableTiming));
+    dl.ev_set[k] = false;
+  }
+  Slot& s = h->slots[0];
+  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
+  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
+  HIPCHK(h, hipDeviceSynchronize());
+  dl.on = true;
+  h->built = h->factored = h->fitted = false;
+  return SIGP_OK;
+}
+
+int sigp_dist_local_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma) {
+  if (!h || !h->dl.on) return fail(h, SIGP_BAD_ARG, "dist_local_build: call dist_local_begin first");
+  if (!(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "sn_tilde >= 0 required");
+  HIPCHK(h, hipSetDevice(h->device));
+  auto& dl = h->dl;
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long n = h->n, n_pad = h->n_pad, dp = h->dp;
+  int rc;
+  h->kernel_id = kernel_id; h->sn_tilde = sn_tilde;
+  if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
+    if (!Sigma || ldsigma < h->d) return fail(h, SIGP_BAD_ARG, "dist_local_build: Sigma required for the reference kernel");
+    h->kp = make_kparams(SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde, 0); h->ell = 0;
+    if ((rc = sigma_prepare(h, Sigma, ldsigma))) return rc;
+    for (int q = 0; q < dl.P; ++q)
+      if (dl.lcol[(size_t)q] >= 0 && (rc = sigma_emit(h, dl_origin(h, q), dl.ncol, q * dl.W, q * dl.W + dl_width(h, q), sn_tilde))) return rc;
+    if ((rc = sigma_kss(h, Sigma, ldsigma))) return rc;
+  } else {
+    if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "bad kernel_id");
+    if (!(ell > 0)) return fail(h, SIGP_BAD_ARG, "ell > 0 required");
+    h->kp = make_kparams(kernel_id, ell, sn_tilde, 0); h->ell = ell;
+    h->kss_unit.assign((size_t)h->m, 1.0);
+    s.kps_host[0] = h->kp;
+    if ((rc = upload_kparams(h, s, 1))) return rc;
+    for (int q = 0; q < dl.P; ++q) {
+      if (dl.lcol[(size_t)q] < 0) continue;
+      const int Wq = dl_width(h, q), J = q * dl.W;
+      double* vo = dl_origin(h, q);
+      ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * Wq * NB * (3.0 * h->d + 20), 8.0 * n * Wq * NB);
+      hipLaunchKernelGGL(kbuild_kernel<double>, dim3((unsigned)Wq, (unsigned)(n_pad / KB_TM), 1), dim3(256), 0, st, h->X, 0L, (int)dp, (int)h->d, (int)n, vo, 0L,
+                         dl.ncol, s.kps, 8, J);
+      hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((Wq * NB + 255) / 256), RIDE, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
+                         (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, vo + n_pad * dl.ncol, 0L, dl.ncol, s.kps, 1, J * NB, Wq * NB);
+      HIPCHK(h, hipGetLastError());
+    }
+  }
+  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), st));
+  if ((rc = sync_slot(h, s))) return rc;
+  return SIGP_OK;
+}
+
+int64_t sigp_dist_local_owner(sigp_handle* h, int64_t p) { return (h && h->dl.on && p >= 0 && p < h->dl.P) ? p % h->dl.world : -1; }
+int64_t sigp_dist_local_panels(sigp_handle* h) { return (h && h->dl.on) ? h->dl.P : 0; }
+
+// owner of panel p: factor it in place (local storage), pack [rows from its diagonal block down x its columns | its inverse
+// diagonal blocks] into dev_buf (sigp_dist_panel_elems(h, p*W, width) elements) and return the LAPACK info so far
+int sigp_dist_local_factor(sigp_handle* h, int64_t p, void* dev_buf, int64_t* info) {
+  if (!h || !h->dl.on || p < 0 || p >= h->dl.P || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_local_factor: bad argument");
+  auto& dl = h->dl;
+  if (dl.lcol[(size_t)p] < 0) return fail(h, SIGP_BAD_ARG, "dist_local_factor: panel %ld belongs to rank %ld", (long)p, (long)(p % dl.world));
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
+  if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
+  const int Wp = dl_width(h, (int)p), J = (int)p * dl.W;
+  int rc = dist_panel<double>(h, s, dl_origin(h, (int)p), dl.ncol, dl.dinv, sp, h->n_pad, J, Wp);
+  if (rc) return rc;
+  const long rows = h->n_pad + RIDE - (long)J * NB, wcols = (long)Wp * NB;
+  double* buf = (double*)dev_buf;
+  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * sizeof(double), dl.mat + (long)J * NB * dl.ncol + dl.lcol[(size_t)p], (size_t)dl.ncol * sizeof(double),
+                             (size_t)wcols * sizeof(double), (size_t)rows, hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, dl.dinv + (long)J * NB * NB, (size_t)Wp * NB * NB * sizeof(double), hipMemcpyDeviceToDevice, sp));
+  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
+  if (h->opt_dist_async) {
+    HIPCHK(h, hipEventRecord(s.ev_pan, sp));
+    HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
+  }
+  HIPCHK(h, hipStreamSynchronize(sp));       // REQUIRED: the caller hands dev_buf to a collective on another stream next
+  if (info) *info = *s.info_host;
+  return SIGP_OK;
+}
+
+// own panel q (> p) -= (panel p)(panel p)^T, panel p read straight from the packed buffer (its owner reads its own pack too).
+// buf_slot (0/1): which receive buffer dev_buf is, for sigp_dist_local_buffer_wait.
+int sigp_dist_local_update(sigp_handle* h, int64_t p, const void* dev_buf, int64_t q, int buf_slot) {
+  if (!h || !h->dl.on || p < 0 || q <= p || q >= h->dl.P || !dev_buf || buf_slot < 0 || buf_slot > 1) return fail(h, SIGP_BAD_ARG, "dist_local_update: bad argument");
+  auto& dl = h->dl;
+  if (dl.lcol[(size_t)q] < 0) return fail(h, SIGP_BAD_ARG, "dist_local_update: panel %ld is not this rank's", (long)q);
+  HIPCHK(h, hipSetDevice(h->device));
+  Slot& s = h->slots[0];
+  const int Wp = dl_width(h, (int)p), Jp = (int)p * dl.W, Wq = dl_width(h, (int)q), Jq = (int)q * dl.W;
+  const int R = (int)(h->n_pad / NB) + 1;
+  const long lda = (long)Wp * NB, o = (long)Jq * NB;
+  GemmArgs g{};
+  g.A = (const double*)dev_buf + (o - (long)Jp * NB) * lda; g.lda = lda;       // rows of panel p from row block Jq down
+  g.B = g.A; g.ldb = lda;
+  g.C = dl_origin(h, (int)q) + o * dl.ncol + o; g.ldc = dl.ncol;
+  g.batch = 1; g.K = Wp * NB; g.r0 = 0; g.r1 = R - Jq; g.c0 = 0; g.c1 = Wq; g.lower = 1;
+  int rc = gemm_sub_auto(h, s.s_upd, g);
+  if (rc) return rc;
+  HIPCHK(h, hipEventRecord(dl.ev_buf[buf_slot], s.s_upd));
+  dl.ev_set[buf_slot] = true;
+  if (h->opt_dist_async) return SIGP_OK;
+  return sync_slot(h, s);
+}
+
+// block until every update that reads receive buffer `buf_slot` has finished (before the next panel is received into it)
+int sigp_dist_local_buffer_wait(sigp_handle* h, int buf_slot) {
+  if (!h || !h->dl.on || buf_slot < 0 || buf_slot > 1) return fail(h, SIGP_BAD_ARG, "dist_local_buffer_wait: bad argument");
+  if (h->dl.ev_set[buf_slot]) HIPCHK(h, hipEventSynchronize(h->dl.ev_buf[buf_slot]));
+  return SIGP_OK;
+}
+
+// partial reductions over this rank's columns: res [512] laid out as epilogue_kernel's (the host sums them over the ranks)
+int sigp_dist_local_reduce(sigp_handle* h, double* res) {
+  if (!h || !h->dl.on || !res) return fail(h, SIGP_BAD_ARG, "dist_local_reduce: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  auto& dl = h->dl;
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  HIPCHK(h, hipStreamSynchronize(s.s_pan));
+  HIPCHK(h, hipMemsetAsync(s.res, 0, 512 * sizeof(double), st));
+  bool any = false;
+  for (auto c : dl.lcol) any = any || c >= 0;
+  if (any) {
+    const double* Z = dl.mat + h->n_pad * dl.ncol;
+    hipLaunchKernelGGL(epilogue_kernel<double>, dim3((unsigned)(h->m + 1), 1), dim3(256), 0, st, Z, dl.ncol, Z, (const double*)nullptr, dl.ncol, (int)h->n,
+                       (int)dl.ncol, (int)(h->m + 1), s.res, 0L, 0L, 0L);
+    for (int q = 0; q < dl.P; ++q)
+      if (dl.lcol[(size_t)q] >= 0)
+        hipLaunchKernelGGL(logdiag_window_kernel, dim3(1), dim3(256), 0, st, (const double*)dl_origin(h, q), dl.ncol, (int)h->n, q * dl.W * NB, dl_width(h, q) * NB, s.res + 256);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  memcpy(res, s.res_host, 512 * sizeof(double));
+  return SIGP_OK;
+}
+
+// res = the ranks' partial reductions summed: sigma_f, nlML, predictions as sigp_fit_predict's out / mean / var
+int sigp_dist_local_results(sigp_handle* h, const double* res, int64_t info, double* out, double* mean, double* var) {
+  if (!h || !h->dl.on || !res || !out) return fail(h, SIGP_BAD_ARG, "dist_local_results: bad argument");
+  finish_results(res, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
+  h->sigma_f = out[0]; h->nlml = out[1];
+  h->built = h->factored = h->fitted = false;      // the factor is spread over the ranks: no general predict / alpha on this handle
+  if (info != 0) return fail(h, SIGP_NOT_SPD, "dist_local_results: matrix is not positive definite (pivot %d)", (int)info);
+  return SIGP_OK;
+}
+
 int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return SIGP_BAD_ARG;
   if (!strcmp(name, "refine_residual")) { *value = h->refine_resid; return SIGP_OK; }
@@ -2000,6 +2243,7 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
     double b = 0;
     for (const auto& s : h->slots) if (s.mat) b += (double)s.capB * (double)(s.cap_npad + RIDE) * (double)s.cap_npad * sizeof(double);
     if (h->fmat) b += (double)(h->cap_f_npad + RIDE) * (double)h->cap_f_npad * sizeof(float);
+    if (h->dl.mat) b += (double)h->dl.cap * sizeof(double);
     *value = b;
     return SIGP_OK;
   }

@@ -32,14 +32,15 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
 template <typename T, bool SET>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
-                                             long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1) {
+                                             long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1,
+                                             int tid_in = -1) {
   const int dbg = dbg_in & DBG_MASK;            // ablation bits: debug library only
   const bool stamp = stamp_in && DBG_MASK != 0;
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v16_t v16_t;
   constexpr int KTe = N_::KT, NE = N_::NE;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
 
@@ -200,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     if (PERSIST) {
       bz = t / g.ntile;
       if (!gemm_tile_coords(g, t - (int)bz * g.ntile, bi, bj)) continue;
+    } else if (g.patch < 0) {
+      if (!gemm_tile_coords_chunked(g, blockIdx.x, bi, bj, bz)) return;
     } else {
       bz = blockIdx.y;
       if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
@@ -212,7 +215,10 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long ph0 = 0, ph1 = 0;
-    syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1);
+    int tid_t = tid;
+    if (PERSIST) asm volatile("" : "+v"(tid_t));   // opaque per tile: keeps the lane-dependent address arithmetic of the tile inside the
+                                                   // loop (hoisted, it costs 18 VGPRs that do not exist: the kernel would spill to scratch)
+    syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
     if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
       __builtin_amdgcn_s_waitcnt(0);
       if (tid == 0) {

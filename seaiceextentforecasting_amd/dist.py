@@ -78,7 +78,7 @@ class DistributedGPR:
 
     Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277)."""
 
-    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True, dtype="f64"):
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True, dtype="f64", owner_only=False):
         from .gpr import GPR
         import torch
         self._torch = torch
@@ -86,7 +86,15 @@ class DistributedGPR:
         self.W = int(outer_blocks)
         self.lookahead = bool(lookahead)
         self.dtype = dtype                     # "f32": fp32 factor sharded the same way, fp64 refinement replicated on every rank (configs[4])
+        # owner_only: a rank allocates, builds and updates only the block columns of its own panels (per-rank matrix bytes
+        # ~ 1/world; received panels are applied straight out of the receive buffer; ride-row reductions are all-reduced).
+        # The factor then stays spread over the ranks: predictions exist for the ride-along points only.
+        self.owner_only = bool(owner_only)
+        if self.owner_only and dtype != "f64":
+            raise ValueError("owner_only sharding is the fp64 engine's (the fp32 refinement needs the whole factor on every rank)")
         self.gp = GPR(kernel=kernel, device=device, dtype=dtype)
+        if self.owner_only:
+            self.gp.set_option("owner_only", 1)
         self.device = device
         self._bufs = [None, None]
 
@@ -107,6 +115,8 @@ class DistributedGPR:
         starts its broadcast while every rank is still applying panel p to the rest of its columns, so the xGMI
         transfer and the owner's latency chain hide behind the trailing update.  Without it the steps
         run strictly one after the other.  Both orders do the same arithmetic: results are bit-identical."""
+        if self.owner_only:
+            return self._fit_owner_only(X, y, ell, sn_tilde, M, Xs)
         from . import _lib as L
         from .gpr import LinAlgError
         torch, gp, lib = self._torch, self.gp, self.gp._lib
@@ -203,5 +213,122 @@ class DistributedGPR:
         self.sigma_f_, self.nlml_, self.sigma_n_ = gp.sigma_f_, gp.nlml_, gp.sigma_n_
         return self
 
+    def _fit_owner_only(self, X, y, ell, sn_tilde, M, Xs):
+        """The same panel loop on owner-only storage (include/sigp.h: sigp_dist_local_*)."""
+        from . import _lib as L
+        from .gpr import LinAlgError
+        torch, gp, lib = self._torch, self.gp, self.gp._lib
+        if Xs is None:
+            raise ValueError("owner_only: pass the test points to fit(Xs=...) -- they ride along the factorisation; the factor itself stays sharded")
+        gp.set_data(X, y, M=M, Xs=Xs)
+        if gp._ride is None:
+            raise ValueError("owner_only: at most %d ride-along test points" % L.MAX_RIDE)
+        gp._check(lib.sigp_dist_local_begin(gp._h, self.W, self.world, self.rank), "dist_local_begin")
+        Sig = None
+        if gp.kernel == "netdiffusion":
+            Sig = L.f64(gp._sigma(float(ell)), 2)
+        gp._check(lib.sigp_dist_local_build(gp._h, gp._kid, float(ell), float(sn_tilde), L.ptr(Sig), 0 if Sig is None else Sig.shape[1]), "dist_local_build")
+        gp.set_option("dist_async", 1 if self.lookahead else 0)
+        T = int(lib.sigp_num_blocks(gp._h))
+        panels = [(J, min(self.W, T - J)) for J in range(0, T, self.W)]
+        P = len(panels)
+        nelem = [int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels]
+        nmax = max(nelem) + 1
+        for k in range(2):
+            if self._bufs[k] is None or self._bufs[k].numel() < nmax:
+                self._bufs[k] = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
+
+        def view(p):
+            return self._bufs[p % 2][:nelem[p] + 1]
+
+        def factor_and_pack(p):
+            pinfo = C.c_int64(0)
+            gp._check(lib.sigp_dist_local_buffer_wait(gp._h, p % 2), "dist_local_buffer_wait")    # updates with panel p-2 are done with the buffer
+            gp._check(lib.sigp_dist_local_factor(gp._h, p, C.c_void_p(view(p).data_ptr()), C.byref(pinfo)), "dist_local_factor")
+            view(p)[nelem[p]] = float(pinfo.value)
+
+        def start_bcast(p):
+            if self.world == 1:
+                return None
+            if self.rank != self.owner(p):
+                gp._check(lib.sigp_dist_local_buffer_wait(gp._h, p % 2), "dist_local_buffer_wait")
+            return self.dist.broadcast(view(p), src=self.owner(p), async_op=True)
+
+        def wait_bcast(work):
+            if work is not None:
+                work.wait()
+            torch.cuda.synchronize(self.device) if not self.lookahead else torch.cuda.current_stream(self.device).synchronize()
+
+        def update(p, q):
+            gp._check(lib.sigp_dist_local_update(gp._h, p, C.c_void_p(view(p).data_ptr()), q, p % 2), "dist_local_update")
+
+        info = 0
+        try:
+            if self.rank == self.owner(0):
+                factor_and_pack(0)
+            work = start_bcast(0)
+            for p in range(P):
+                wait_bcast(work)
+                work = None
+                info = int(view(p)[nelem[p]].item())
+                if info != 0:
+                    break
+                mine = [q for q in range(p + 1, P) if self.owner(q) == self.rank]
+                nxt = p + 1
+                if self.lookahead and nxt < P:
+                    if self.owner(nxt) == self.rank:
+                        update(p, nxt)                         # the next panel's own columns first ...
+                        gp._check(lib.sigp_dist_mark(gp._h), "dist_mark")
+                        mine.remove(nxt)
+                        for q in mine:
+                            update(p, q)
+                        mine = []
+                        factor_and_pack(nxt)                   # ... the panel stream factors and packs panel p+1 meanwhile
+                    work = start_bcast(nxt)
+                for q in mine:
+                    update(p, q)
+                if not self.lookahead and nxt < P:
+                    if self.owner(nxt) == self.rank:
+                        factor_and_pack(nxt)
+                    work = start_bcast(nxt)
+            if work is not None:
+                wait_bcast(work)
+        finally:
+            gp._check(lib.sigp_dist_sync(gp._h, 0), "dist_sync")
+            gp.set_option("dist_async", 0)
+        res = np.zeros(512)
+        gp._check(lib.sigp_dist_local_reduce(gp._h, L.ptr(res)), "dist_local_reduce")
+        if self.world > 1:                                      # the one exchange besides the panel broadcast: 512 doubles
+            t = torch.from_numpy(res)
+            if self.dist.get_backend() == "nccl":
+                t = t.cuda(self.device)
+            self.dist.all_reduce(t)
+            res = t.cpu().numpy().copy()
+        out = np.zeros(4)
+        m = gp._ride.shape[0]
+        mean, var = np.zeros(max(m, 1)), np.zeros(max(m, 1))
+        rc = lib.sigp_dist_local_results(gp._h, L.ptr(res), info, L.ptr(out), L.ptr(mean), L.ptr(var))
+        gp.info_ = info
+        if rc == L.NOT_SPD:
+            raise LinAlgError("Matrix is not positive definite (pivot %d)" % info, info)
+        gp._check(rc, "dist_local_results")
+        gp.sigma_f_, gp.nlml_, gp.sigma_n_ = float(out[0]), float(out[1]), float(out[3])
+        gp._ride_mean, gp._ride_var = mean[:m].copy(), var[:m].copy()
+        gp._fitted = False
+        self._own_ride = (gp._ride.copy(), gp._ride_mean, gp._ride_var)
+        self.sigma_f_, self.nlml_, self.sigma_n_ = gp.sigma_f_, gp.nlml_, gp.sigma_n_
+        return self
+
+    @property
+    def matrix_bytes_(self):
+        """Device bytes this rank holds in matrix / factor buffers (owner_only: ~ 1/world of the replicated form)."""
+        return self.gp.matrix_bytes_
+
     def predict(self, Xs):
+        if self.owner_only:
+            ride, mu, var = self._own_ride
+            Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
+            if Xs.shape != ride.shape or not np.array_equal(Xs, ride):
+                raise RuntimeError("owner_only: the factor is spread over the ranks; predictions exist for the points passed to fit(Xs=...)")
+            return mu.copy(), var.copy()
         return self.gp.predict(Xs)

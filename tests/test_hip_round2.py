@@ -388,6 +388,77 @@ def test_rccl_backend_world1(tmp_path):
     assert (tmp_path / "ok_0").exists()
 
 
+_OWNER_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import torch, torch.distributed as dist
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")          # ranks share the box's single GPU: gloo moves the panels (RCCL needs one device per rank)
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("matern52", 1100, 4, 3), ("rbf", 300, 3, 4)):
+    X, y, Xs = O.synthetic_problem(n, d, 4242 + n, m=3)
+    ell, sn = (np.sqrt(d), 1e-2) if kind != "netdiffusion" else (0.05, 1e-2)
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    full = None
+    with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=True) as dg:
+        dg.fit(X, y, ell, sn, Xs=Xs)
+        full = (dg.predict(Xs), dg.nlml_, dg.matrix_bytes_)
+    for la in (True, False):
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la, owner_only=True) as dg:
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank, la, rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
+            assert rel(dg.nlml_, ref["nlml"]) <= 1e-9 and rel(dg.sigma_f_, ref["sigma_f"]) <= 1e-9, (kind, rank, la)
+            assert rel(mu, full[0][0]) <= 1e-12 and rel(dg.nlml_, full[1]) <= 1e-13      # same arithmetic as the replicated form
+            # per-rank matrix bytes ~ 1/world of the replicated form (block-cyclic shares differ by at most one panel)
+            T = -(-n // 128); P = -(-T // W)
+            mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
+            assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 8) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)
+            if world > 1 and T >= 4 * W:
+                assert dg.matrix_bytes_ <= 0.75 * full[2], (dg.matrix_bytes_, full[2])
+            try:
+                dg.predict(Xs + 1.0)
+                raise SystemExit("expected RuntimeError")
+            except RuntimeError:
+                pass
+            dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
+            assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
+# non-SPD: every rank learns the pivot from the broadcast panel
+X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
+X[300:350] = X[100:150]
+for la in (True, False):
+    with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=2, lookahead=la, owner_only=True) as dg:
+        try:
+            dg.fit(X, y, 2.0, 0.0, Xs=Xs)
+            raise SystemExit("expected LinAlgError")
+        except np.linalg.LinAlgError as e:
+            assert 300 < e.info <= 350, e.info
+        dg.fit(X, y, 2.0, 1e-2, Xs=Xs)
+        assert np.isfinite(dg.nlml_)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+'''
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_cholesky_owner_only_storage(tmp_path, world):
+    """configs[3] path with owner-only storage at test size: every rank allocates, builds and updates only its own block
+    columns (matrix bytes ~ 1/world), applies received panels from the receive buffer and all-reduces the ride-row
+    reductions; == oracle and == the replicated form on every rank (gloo between processes sharing the one GPU)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_OWNER_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    port = 29700 + (os.getpid() % 150) + world
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert (tmp_path / ("ok_%d" % r)).exists()
+
+
 def test_bench_gpus_flag_fails_loudly_without_enough_gpus():
     """`python bench.py --gpus N` on a box with fewer than N GPUs must not silently measure one GPU."""
     import torch
