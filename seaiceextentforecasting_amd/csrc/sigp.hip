@@ -98,7 +98,8 @@ struct sigp_handle {
   double* sm_lam = nullptr; long cap_sm_lam = 0;
   SmallProb* sm_probs = nullptr; long cap_sm_probs = 0;
   double* sm_out = nullptr; long cap_sm_out = 0;   // [nprob][4 + 2*mstride]
-  int sm_ch = 32, sm_mmax = 0; long sm_lds = 0;
+  int sm_ch = 32, sm_mmax = 0, sm_nmax = 0; long sm_lds = 0;
+  int opt_small_nt64 = 0;                     // measurement switch: one wavefront per fit at orders <= 64
   // owner-only sharding of one large fit (sigp_dist_local_*): this rank's block columns only
   struct DistLocal {
     bool on = false;
@@ -1062,6 +1063,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "small_nt64")) { h->opt_small_nt64 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
@@ -1070,7 +1072,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "group")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "group")) { if (value < 1 || value > 256) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
   if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value > 64) return SIGP_BAD_ARG;
@@ -1549,7 +1551,7 @@ int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t st
 }
 
 int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency) {
-  if (!h || h->b_count == 0 || group < 1 || group > 64 || concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_reserve: bad argument");
+  if (!h || h->b_count == 0 || group < 1 || group > 256 || concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_reserve: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
   if (h->dtype == SIGP_F32) return f32_reserve(h, h->b_npad);
   for (int k = 0; k < concurrency; ++k) {
@@ -1786,7 +1788,7 @@ int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int
   HIPCHK(h, hipMemcpy(h->sm_y, y_pool, (size_t)toty * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(h, hipMemcpy(h->sm_lam, lam_pool, (size_t)totl * sizeof(double), hipMemcpyHostToDevice));
   h->sm_sets.swap(sets);
-  h->sm_ch = ch; h->sm_mmax = mmax; h->sm_lds = smallgp_lds_bytes(nmax, mmax, ch);
+  h->sm_ch = ch; h->sm_mmax = mmax; h->sm_nmax = nmax; h->sm_lds = smallgp_lds_bytes(nmax, mmax, ch);
   return SIGP_OK;
 }
 
@@ -1815,8 +1817,9 @@ int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, cons
   hipStream_t st = h->slots[0].s_upd;
   HIPCHK(h, hipMemcpyAsync(h->sm_probs, probs.data(), probs.size() * sizeof(SmallProb), hipMemcpyHostToDevice, st));
   HIPCHK(h, hipMemsetAsync(h->sm_out, 0xff, (size_t)(nprob * per) * sizeof(double), st));   // NaN wherever a set has fewer test points than mstride
-  static AttrOnce attr;
-  HIPCHK(h, attr.set(h->device, (const void*)smallgp_kernel, 160 * 1024 - 64));
+  static AttrOnce attr64, attr256;
+  HIPCHK(h, attr64.set(h->device, (const void*)smallgp_kernel<64>, 160 * 1024 - 64));
+  HIPCHK(h, attr256.set(h->device, (const void*)smallgp_kernel<256>, 160 * 1024 - 64));
   double* d_out = h->sm_out;
   double* d_mean = h->sm_out + nprob * 4;
   double* d_var = d_mean + nprob * ms;
@@ -1824,8 +1827,14 @@ int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, cons
     double fl = 0;
     for (const auto& pb : probs) { const SmallSet& s = h->sm_sets[(size_t)pb.set]; fl += (double)s.n * s.n * s.N + (double)s.n * s.n * s.n / 3 + 2.0 * s.n * s.n * (1 + s.m); }
     ProfScope ps(h, st, SIGP_KC_SMALL, fl, 0.0);
-    hipLaunchKernelGGL(smallgp_kernel, dim3((unsigned)nprob), dim3(256), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
-                       h->sm_ch, d_out, d_mean, d_var, (int)ms);
+    // orders up to 64 (the reference's n <= 45): one wavefront per fit; larger: four
+    // measured on the reference-size grid (48 000 fits, n = 6 .. 45): four wavefronts per fit 1.02 ms, one wavefront per fit 1.71 ms
+    if (h->sm_nmax <= 64 && h->opt_small_nt64)
+      hipLaunchKernelGGL(smallgp_kernel<64>, dim3((unsigned)nprob), dim3(64), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
+                         h->sm_ch, d_out, d_mean, d_var, (int)ms);
+    else
+      hipLaunchKernelGGL(smallgp_kernel<256>, dim3((unsigned)nprob), dim3(256), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
+                         h->sm_ch, d_out, d_mean, d_var, (int)ms);
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)nprob * 4 * sizeof(double), hipMemcpyDeviceToHost, st));

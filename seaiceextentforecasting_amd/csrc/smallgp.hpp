@@ -43,18 +43,27 @@ inline long smallgp_lds_bytes(int n, int m, int ch) {
   return ((long)(n + 1 + m) * ldk + (long)(n + m) * (ch + 1) + ch + 4 * SM_MMAX + 16) * (long)sizeof(double);
 }
 
-// sum over the 256 threads; result valid on every thread
+// sum over the NT threads of the workgroup; result valid on every thread
+template <int NT>
 __device__ inline double smallgp_allsum(double v, double* sh) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
   __syncthreads();
-  return sh[0] + sh[1] + sh[2] + sh[3];
+  double t = sh[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) t += sh[w];
+  return t;
 }
 
 // out [nprob][4] = sigma_f, nlML, info (LAPACK pivot index, 0 = ok), sigma_n;  mean / var [nprob][mstride]
-__global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict__ sets, const SmallProb* __restrict__ probs,
+// NT = threads per workgroup: 256 (four wavefronts per fit) is the default at every order; NT = 64 (one wavefront per fit, every
+// barrier of the column loop a wave-local no-op) is kept as a measurement switch ("small_nt64") -- on the reference-size grid it
+// is SLOWER (1.71 vs 1.02 ms for 48 000 fits of n = 6 .. 45): the rank-1 updates have ~n^2/2 elements, enough for four waves,
+// and one resident wave per fit leaves the LDS pipeline idle between dependent steps.
+template <int NT>
+__global__ __launch_bounds__(NT) void smallgp_kernel(const SmallSet* __restrict__ sets, const SmallProb* __restrict__ probs,
                                                       const double* __restrict__ Apool, const double* __restrict__ ypool,
                                                       const double* __restrict__ lampool, int ch, double* __restrict__ out,
                                                       double* __restrict__ mean, double* __restrict__ var, int mstride) {
@@ -71,11 +80,12 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
   double* kss = wk + ch;                          // [SM_MMAX] k~**_j
   double* red = kss + SM_MMAX;                    // reduction scratch
   __shared__ int s_info;
+  constexpr int TY = NT / 16;       // thread rows of the 16-wide element mapping
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const double* A = Apool + st.a_off;
   const double* lam = lampool + st.lam_off;
 
-  for (int e = tid; e < R * ldk; e += 256) Kp[e] = 0.0;
+  for (int e = tid; e < R * ldk; e += NT) Kp[e] = 0.0;
   if (tid < SM_MMAX) kss[tid] = 0.0;
   if (tid == 0) s_info = 0;
 
@@ -88,12 +98,12 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
       wk[tid] = sqrt(st.lam_mode ? fmax(l, 0.0) : exp(pb.ell * l));
     }
     __syncthreads();
-    for (int e = tid; e < (n + m) * kc; e += 256) {
+    for (int e = tid; e < (n + m) * kc; e += NT) {
       const int r = e / kc, k = e - r * kc;
       Ac[r * lda + k] = A[(long)r * N + k0 + k] * wk[k];
     }
     __syncthreads();
-    for (int i = ty; i < n + m; i += 16) {
+    for (int i = ty; i < n + m; i += TY) {
       const int krow = i < n ? i : i + 1;               // test rows sit below the y row
       const double* ai = Ac + i * lda;
       const int jmax = i < n ? i : n - 1;
@@ -112,9 +122,9 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
     }
   }
   __syncthreads();
-  if (tid < n) {
-    Kp[tid * ldk + tid] += pb.sn;
-    Kp[n * ldk + tid] = ypool[st.y_off + tid];
+  for (int i = tid; i < n; i += NT) {
+    Kp[i * ldk + i] += pb.sn;
+    Kp[n * ldk + i] = ypool[st.y_off + i];
   }
   __syncthreads();
 
@@ -127,9 +137,9 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
     }
     const double s = sqrt(d), inv = 1.0 / s;
     __syncthreads();                // everyone has read the pivot
-    for (int i = j + tid; i < R; i += 256) Kp[i * ldk + j] = (i == j) ? s : Kp[i * ldk + j] * inv;
+    for (int i = j + tid; i < R; i += NT) Kp[i * ldk + j] = (i == j) ? s : Kp[i * ldk + j] * inv;
     __syncthreads();
-    for (int i = j + 1 + ty; i < R; i += 16) {
+    for (int i = j + 1 + ty; i < R; i += TY) {
       const double lij = Kp[i * ldk + j];
       const int cmax = i < n ? i : n - 1;
       for (int c = j + 1 + tx; c <= cmax; c += 16) Kp[i * ldk + c] = fma(-lij, Kp[c * ldk + j], Kp[i * ldk + c]);
@@ -139,9 +149,10 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
 
   // ---- reductions: sigma_f, nlML, mean, variance (north/June1st.py:267-268, 246, 276-277) ------------------------
   const double* z = Kp + n * ldk;
-  const double zi = tid < n ? z[tid] : 0.0;
-  const double zz = smallgp_allsum(zi * zi, red);
-  const double logdet = smallgp_allsum(tid < n ? log(Kp[tid * ldk + tid]) : 0.0, red);
+  double zq = 0.0, ld_ = 0.0;
+  for (int i = tid; i < n; i += NT) { zq = fma(z[i], z[i], zq); ld_ += log(Kp[i * ldk + i]); }
+  const double zz = smallgp_allsum<NT>(zq, red);
+  const double logdet = smallgp_allsum<NT>(ld_, red);
   const int info = s_info;
   const double inf = __builtin_huge_val(), qnan = __builtin_nan("");
   const double sf = zz / (double)n;
@@ -157,9 +168,11 @@ __global__ __launch_bounds__(256) void smallgp_kernel(const SmallSet* __restrict
     }
   }
   for (int j = 0; j < m; ++j) {
-    const double vi = tid < n ? Kp[(n + 1 + j) * ldk + tid] : 0.0;
-    const double vz = smallgp_allsum(vi * zi, red);
-    const double vv = smallgp_allsum(vi * vi, red);
+    const double* v = Kp + (n + 1 + j) * ldk;
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < n; i += NT) { a = fma(v[i], z[i], a); b = fma(v[i], v[i], b); }
+    const double vz = smallgp_allsum<NT>(a, red);
+    const double vv = smallgp_allsum<NT>(b, red);
     if (tid == 0) {
       mean[(long)blockIdx.x * mstride + j] = info == 0 ? vz : qnan;
       var[(long)blockIdx.x * mstride + j] = info == 0 ? sf * (kss[j] + pb.sn - vv) : qnan;

@@ -1,11 +1,11 @@
 """Summarise the rocprofv3 --pmc passes of tools/collect_profiles.sh into profiles/<round>_pmc_syrk128.json."""
 import json, sys
 import pandas as pd
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 base = "gpurun_out/%s/" % rnd
 out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile  (one pass per counter set)",
-       "kernel": "sigp::syrk128_kernel<double, false>", "notes": []}
-sel = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<double, false>", regex=False)]
+       "kernel": "sigp::syrk128_kernel<double, false, false>", "notes": []}
+sel = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<double, false", regex=False)]   # the trailing / inner updates (not the SET = true panel solve)
 fe = sel(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
 wr = sel(pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv"))
 mf = sel(pd.read_csv(base + "pmc_mfma/bench_counter_collection.csv"))
