@@ -321,3 +321,17 @@ def test_bench_grid_and_strong_scaling_bookkeeping():
             assert np.array_equal(yr, np.tile(yr[:period], len(yr) // period + 1)[:len(yr)])     # what run_batch's (first + i) % sets assumes
             seen += list(mine)
         assert sorted(seen) == list(range(steps * G))
+
+
+def test_asan_build_of_the_shim_rejects_bad_arguments_cleanly():
+    """SURVEY 5 (sanitizers): host-side AddressSanitizer build of the C shim (make asan; GPU ASan is unavailable on the pool) --
+    every entry point called with a null handle / bad sizes under ASan: clean rejections, no sanitizer report."""
+    csrc = os.path.join(ROOT, "seaiceextentforecasting_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan"], stdout=subprocess.DEVNULL)
+    rt = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no ASan runtime in this image")
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asan_negative_paths.py")], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode == 0 and "asan negative paths ok" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    assert "AddressSanitizer" not in p.stderr
