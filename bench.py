@@ -325,6 +325,25 @@ def other_configs(local):
     single("configs[1] n=4096 d=8 fp64 RBF single fit", "rbf", "f64", 4096, 8, np.sqrt(8.0), 1e-2, 20240001, 5, PEAK_F64_MFMA_TFLOPS)
     single("configs[3] n=16384 d=16 fp64 RBF single fit on one GPU", "rbf", "f64", 16384, 16, 4.0, 1e-2, 20240003, 2, PEAK_F64_MFMA_TFLOPS)
     single("configs[4] n=32768 d=32 fp32 Matern-5/2 + fp64 refinement on one GPU", "matern52", "f32", 32768, 32, np.sqrt(32.0), 1e-1, 20240004, 2, PEAK_F32_MFMA_TFLOPS)
+    # configs[4] shape in a lockstep group of 4 (one build + one blocked fp32 Cholesky over the members, refinement member by member)
+    try:
+        n4, d4, G4 = 32768, 32, 4
+        Xb = np.zeros((G4, n4, d4)); yb = np.zeros((G4, n4)); Xsb = np.zeros((G4, 1, d4))
+        for b in range(G4):
+            Xb[b], yb[b], Xsb[b] = synthetic_problem(n4, d4, 20240004 + b, m=1)
+        with GPR(kernel="matern52", dtype="f32", device=local) as g:
+            e4 = np.full(G4, np.sqrt(d4)); s4 = np.full(G4, 1e-1)
+            g.upload_batch(Xb, yb, Xsb, group=G4, concurrency=1)
+            g.run_batch(0, G4, e4, s4, concurrency=1, group=G4)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            r4 = g.run_batch(0, G4, e4, s4, concurrency=1, group=G4)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / G4
+        assert np.all(r4["info"] == 0)
+        rec["configs[4] shape, lockstep group of 4 on one GPU"] = {"ms_per_fit": 1e3 * dt, "fits_per_s": 1.0 / dt, "tflops": flops_per_fit(n4, d4) / dt / 1e12,
+                                                                 "frac_of_peak": flops_per_fit(n4, d4) / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, "peak_tflops": PEAK_F32_MFMA_TFLOPS}
+        del Xb, yb, Xsb
+    except Exception as e:                       # an extra record must never cost the metric line
+        rec["configs[4] shape, lockstep group of 4 on one GPU"] = {"error": str(e)[:200]}
     # MLII: nlML + exact gradient (north/June1st.py:235-257 with the true derivative), the O(n^3) hot spot of an optimiser run
     ml = {}
     for n in (4096, 8192):

@@ -74,7 +74,7 @@ struct sigp_handle {
   double* gSig = nullptr; long cap_gSig = 0;  // MLII gradient (reference kernel): M Sigma~ padded [dp][dp] and X (M Sigma~) [n_pad][dp] --
   double* gT = nullptr; long cap_gT = 0;      // separate from Sig / T, which sigp_predict reads after a fit
   // fp32 engine (dtype == SIGP_F32): fp32 factor + fp64 iterative refinement (BASELINE configs[4])
-  float* fmat = nullptr; float* fdinv = nullptr; float* fZ = nullptr; long cap_f_npad = 0;
+  float* fmat = nullptr; float* fdinv = nullptr; float* fZ = nullptr; long cap_f_npad = 0; int cap_f_G = 0;
   float* fU = nullptr; float* fV = nullptr;  // [n_pad][n_pad] each: inverse-transposes of the factor's 2048-column diagonal blocks (fU, upper) and their
                                              // transposes (fV, lower) for the block triangular solves of the refinement; only the diagonal big blocks are used
   float* fXw = nullptr;                      // [4][n_pad] second working row set of those solves
@@ -794,15 +794,17 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* din
 // ---- fp32 engine: fp32 kernel matrix + Cholesky, fp64 iterative refinement of alpha~ and w_j -----------------
 // (BASELINE configs[4]; no reference counterpart -- the reference is fp64 NumPy.  Same outputs as the fp64 path:
 //  sigma_f, nlML, mean, var of north/June1st.py:267-277, 246.)
-int f32_reserve(sigp_handle* h, long n_pad) {
-  if (h->cap_f_npad >= n_pad) return SIGP_OK;
+int f32_reserve(sigp_handle* h, long n_pad, int G = 1) {
+  if (h->cap_f_npad >= n_pad && h->cap_f_G >= G) return SIGP_OK;
+  n_pad = std::max(n_pad, h->cap_f_npad); G = std::max(G, h->cap_f_G);
   HIPCHK(h, hipDeviceSynchronize());
   for (float** p : {&h->fmat, &h->fdinv, &h->fZ, &h->fU, &h->fV, &h->fXw}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
   for (double** p : {&h->xq, &h->rq, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-  h->cap_f_npad = 0;
-  HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)(n_pad + RIDE) * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fdinv, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
-  HIPCHK(h, hipMemset(h->fdinv, 0, (size_t)(n_pad / NB) * NB * NB * sizeof(float)));
+  h->cap_f_npad = 0; h->cap_f_G = 0;
+  // G lockstep members of the factor (batch path); the solve / refinement workspaces below serve one member at a time
+  HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)G * (n_pad + RIDE) * n_pad * sizeof(float)));
+  HIPCHK(h, hipMalloc((void**)&h->fdinv, (size_t)G * (n_pad / NB) * NB * NB * sizeof(float)));
+  HIPCHK(h, hipMemset(h->fdinv, 0, (size_t)G * (n_pad / NB) * NB * NB * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->fZ, (size_t)RIDE * n_pad * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->fU, (size_t)n_pad * n_pad * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->fV, (size_t)n_pad * n_pad * sizeof(float)));
@@ -811,7 +813,7 @@ int f32_reserve(sigp_handle* h, long n_pad) {
   HIPCHK(h, hipMalloc((void**)&h->rq, (size_t)4 * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->fpart, (size_t)(n_pad / 256 + 1) * 8 * sizeof(double)));
   HIPCHK(h, hipDeviceSynchronize());
-  h->cap_f_npad = n_pad;
+  h->cap_f_npad = n_pad; h->cap_f_G = G;
   return SIGP_OK;
 }
 
@@ -889,8 +891,9 @@ int f32_block_backward(sigp_handle* h, hipStream_t st, long n_pad, int nrhs, flo
   return SIGP_OK;
 }
 
+// `member`: which lockstep member's reductions / info to use (h->fmat / h->fdinv already point at that member's factor)
 int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
-               long dp, long n_pad, long m, double* out, double* mean, double* var) {
+               long dp, long n_pad, long m, double* out, double* mean, double* var, int member = 0) {
   Slot& s = h->slots[0];
   hipStream_t st = s.s_upd;
   const long ld = n_pad;
@@ -900,11 +903,11 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
   {
     const float* Z = h->fmat + n_pad * ld;
     hipLaunchKernelGGL(epilogue_kernel<float>, dim3((unsigned)(m + 2), 1), dim3(256), 0, st, Z, ld, Z, (const float*)h->fmat, ld, (int)n,
-                       (int)n_pad, (int)(m + 1), s.res, 0L, 0L, 0L);
+                       (int)n_pad, (int)(m + 1), s.res + 512 * member, 0L, 0L, 0L);
     HIPCHK(h, hipGetLastError());
   }
-  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(s.res_host + 512 * member, s.res + 512 * member, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipMemcpyAsync(s.info_host + member, s.info + member, sizeof(int), hipMemcpyDeviceToHost, st));
   // inverse-transposes of the factor's 2048-column diagonal blocks (fU) and their transposes (fV; it is the scratch of the
   // inversion first), for the block triangular solves below
   {
@@ -951,7 +954,7 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
   HIPCHK(h, hipMemcpyAsync(r0.data(), h->rq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipMemcpyAsync(yh.data(), y, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
   HIPCHK(h, hipStreamSynchronize(st));
-  const int info = *s.info_host;
+  const int info = s.info_host[member];
   const double inf = std::numeric_limits<double>::infinity();
   if (info != 0) {
     out[0] = inf; out[1] = inf; out[2] = (double)info; out[3] = inf;
@@ -966,7 +969,7 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
   h->refine_resid = ymax > 0 ? rmax / ymax : 0.0;
   const double sf = dots0[0] / (double)n;                                   // y^T alpha~ / n
   out[0] = sf;
-  out[1] = 0.5 * n + s.res_host[256] + 0.5 * n * std::log(sf) + 0.5 * n * std::log(2.0 * M_PI);   // log-det from the fp32 factor
+  out[1] = 0.5 * n + s.res_host[512 * member + 256] + 0.5 * n * std::log(sf) + 0.5 * n * std::log(2.0 * M_PI);   // log-det from the fp32 factor
   out[2] = 0.0; out[3] = sf * sn;
   for (long j = 0; j < m; ++j) {
     if (mean) mean[j] = dots0[1 + j];                                       // k*^T alpha~
@@ -981,6 +984,40 @@ int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* 
   if (rc) return rc;
   if ((rc = potrf_core<float>(h, h->slots[0], h->fmat, 0, h->fdinv, 0, 1, n_pad))) return rc;
   return f32_finish(h, kernel_id, ell, sn, X, y, Xs, n, d, dp, n_pad, m, out, mean, var);
+}
+
+// nb fp32 fits of equal order in lockstep (batch path): one covariance build and one blocked Cholesky over all members
+// (grid.y / grid.z = member, as the fp64 lockstep batches), then the solves + fp64 refinement member by member (they are
+// HBM-bound streams of one factor each and share the workspaces).  kps_host[b] holds member b's hyper-parameters / data set.
+int f32_fit_lockstep(sigp_handle* h, int nb, int kernel_id, const double* ell, const double* sn, const long* ds, const double* bX, const double* by,
+                     const double* bXs, long n, long d, long dp, long n_pad, long m, double* out, double* mean, double* var) {
+  if (m > 3) return fail(h, SIGP_BAD_ARG, "fp32 engine: at most 3 ride-along test points (refinement solves 1+m systems)");
+  if (d > 64) return fail(h, SIGP_BAD_ARG, "fp32 engine: d <= 64 required");
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  const long ld = n_pad, fStride = (n_pad + RIDE) * n_pad, dStride = (n_pad / NB) * NB * NB;
+  int rc;
+  if ((rc = f32_reserve(h, n_pad, nb))) return rc;
+  if ((rc = slot_reserve(h, s, NB, nb))) return rc;     // res / info / kps buffers for nb members
+  for (int b = 0; b < nb; ++b) s.kps_host[b] = make_kparams(kernel_id, ell[b], sn[b], (int)ds[b]);
+  if ((rc = upload_kparams(h, s, nb))) return rc;
+  {
+    ProfScope ps(h, st, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 2.0 * n * (n + 1)));
+    hipLaunchKernelGGL(kbuild_kernel<float>, dim3((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb), dim3(256), 0, st, bX, n_pad * dp, (int)dp, (int)d, (int)n, h->fmat,
+                       fStride, ld, s.kps, 0);
+    hipLaunchKernelGGL(ride_build_kernel<float>, dim3((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb), dim3(256), 0, st, bX, n_pad * dp, bXs, (long)RIDE * dp, by, n_pad,
+                       (int)dp, (int)d, (int)n, (int)n_pad, (int)m, 1, h->fmat + n_pad * ld, fStride, ld, s.kps, 1);
+    HIPCHK(h, hipGetLastError());
+  }
+  if ((rc = potrf_core<float>(h, s, h->fmat, fStride, h->fdinv, dStride, nb, n_pad))) return rc;
+  float* const fm0 = h->fmat; float* const fd0 = h->fdinv;
+  for (int b = 0; b < nb && !rc; ++b) {
+    h->fmat = fm0 + b * fStride; h->fdinv = fd0 + b * dStride;        // view of member b for the solve / refinement code
+    rc = f32_finish(h, kernel_id, ell[b], sn[b], bX + ds[b] * n_pad * dp, by + ds[b] * n_pad, bXs + ds[b] * (long)RIDE * dp, n, d, dp, n_pad, m, out + 4 * b,
+                    mean ? mean + b * m : nullptr, var ? var + b * m : nullptr, b);
+  }
+  h->fmat = fm0; h->fdinv = fd0;
+  return rc;
 }
 
 int sync_slot(sigp_handle* h, Slot& s) {
@@ -1556,7 +1593,7 @@ int sigp_batch_upload(sigp_handle* h, int64_t batch, const double* X, int64_t st
 int sigp_batch_reserve(sigp_handle* h, int64_t group, int concurrency) {
   if (!h || h->b_count == 0 || group < 1 || group > 256 || concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_reserve: bad argument");
   HIPCHK(h, hipSetDevice(h->device));
-  if (h->dtype == SIGP_F32) return f32_reserve(h, h->b_npad);
+  if (h->dtype == SIGP_F32) return f32_reserve(h, h->b_npad, (int)group);
   for (int k = 0; k < concurrency; ++k) {
     int rc = slot_reserve(h, h->slots[k], h->b_npad, (int)group);
     if (rc) return rc;
@@ -1573,12 +1610,16 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
   if (concurrency < 1 || concurrency > MAX_SLOTS) return fail(h, SIGP_BAD_ARG, "batch_run: concurrency must be 1..16");
   HIPCHK(h, hipSetDevice(h->device));
   const long n = h->b_n, d = h->b_d, dp = h->b_dp, m = h->b_m, n_pad = h->b_npad;
-  if (h->dtype == SIGP_F32) {   // fp32 engine: one fit at a time (factor + refinement), data sets resident in HBM
-    for (long i = 0; i < count; ++i) {
+  if (h->dtype == SIGP_F32) {   // fp32 engine: lockstep groups for the factorisation, refinement member by member; data sets resident in HBM
+    for (long i = 0; i < count; ++i)
       if (!(ell[i] > 0) || !(sn_tilde[i] >= 0)) return fail(h, SIGP_BAD_ARG, "batch_run: ell > 0 and sn_tilde >= 0 required");
-      const long ds = (first + i) % h->b_count;
-      int rc32 = f32_fit(h, kernel_id, ell[i], sn_tilde[i], h->bX + ds * n_pad * dp, h->by + ds * n_pad, h->bXs + ds * (long)RIDE * dp, n, d, dp,
-                         n_pad, m, out + 4 * i, mean ? mean + i * m : nullptr, var ? var + i * m : nullptr);
+    const int G32 = (int)std::max<long>(1, std::min<long>(h->opt_group, count));
+    std::vector<long> dsv((size_t)G32);
+    for (long g0 = 0; g0 < count; g0 += G32) {
+      const int nb = (int)std::min<long>(G32, count - g0);
+      for (int b = 0; b < nb; ++b) dsv[(size_t)b] = (first + g0 + b) % h->b_count;
+      int rc32 = f32_fit_lockstep(h, nb, kernel_id, ell + g0, sn_tilde + g0, dsv.data(), h->bX, h->by, h->bXs, n, d, dp, n_pad, m, out + 4 * g0,
+                                  mean ? mean + g0 * m : nullptr, var ? var + g0 * m : nullptr);
       if (rc32) return rc32;
     }
     h->built = h->factored = h->fitted = false;
@@ -2254,7 +2295,7 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   if (!strcmp(name, "matrix_bytes")) {
     double b = 0;
     for (const auto& s : h->slots) if (s.mat) b += (double)s.capB * (double)(s.cap_npad + RIDE) * (double)s.cap_npad * sizeof(double);
-    if (h->fmat) b += (double)(h->cap_f_npad + RIDE) * (double)h->cap_f_npad * sizeof(float);
+    if (h->fmat) b += (double)std::max(1, h->cap_f_G) * (double)(h->cap_f_npad + RIDE) * (double)h->cap_f_npad * sizeof(float);
     if (h->dl.mat) b += (double)h->dl.cap * sizeof(double);
     *value = b;
     return SIGP_OK;

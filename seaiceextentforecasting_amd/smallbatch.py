@@ -29,6 +29,7 @@ class SmallBatch:
         self._sets = []          # device sets: (A, y, lam, mode)
         self._set_of = {}        # (ds, None) or (ds, ell) -> device set index
         self._fits = []          # (device set, ell, sn)
+        self._packed = None      # the fit list as arrays (rebuilt after add_fit)
         self._uploaded = 0
 
     # ---- building the list ---------------------------------------------------------------------------------------
@@ -83,6 +84,7 @@ class SmallBatch:
         if not (float(ell) > 0) or not (float(sn_tilde) >= 0):
             raise ValueError("ell > 0 and sn_tilde >= 0 required")
         self._fits.append((self._device_set(ds, ell, expm), float(ell), float(sn_tilde)))
+        self._packed = None
         return len(self._fits) - 1
 
     # ---- device ---------------------------------------------------------------------------------------------------
@@ -112,9 +114,10 @@ class SmallBatch:
         if self._uploaded != len(self._sets):
             self.upload()
         F = len(self._fits)
-        si = np.array([f[0] for f in self._fits], dtype=np.int64)
-        ell = np.array([f[1] for f in self._fits], dtype=np.float64)
-        sn = np.array([f[2] for f in self._fits], dtype=np.float64)
+        if self._packed is None:
+            arr = np.asarray(self._fits, dtype=np.float64)
+            self._packed = (np.ascontiguousarray(arr[:, 0], dtype=np.int64), np.ascontiguousarray(arr[:, 1]), np.ascontiguousarray(arr[:, 2]))
+        si, ell, sn = self._packed
         ms = max(self._mmax, 1)
         out = np.zeros((F, 4)); mean = np.full((F, ms), np.nan); var = np.full((F, ms), np.nan)
         gp = self.gp

@@ -267,6 +267,35 @@ def test_mlii_gradient_at_multi_block_sizes(S, kind, n, d):
     assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= max(TOL_PRED, 1e-6 * float(np.exp(th[1])))
 
 
+def test_fp32_lockstep_batch_matches_oracle(S):
+    """fp32 engine, batch path: the factorisations of a group run in lockstep (one build, one blocked Cholesky over all
+    members), the refinement member by member.  Different data sets and hyper-parameters per member, a non-SPD member
+    isolated, a ragged last group; tolerances of the fp32 engine (mean / sigma_f <= 1e-6, nlML <= 1e-5 vs the fp64 oracle)."""
+    n, d, B, F = 900, 6, 3, 7
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 2, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 640 + b, m=2)
+    Xb[1, 500:560] = Xb[1, 100:160]                    # data set 1 is singular without noise
+    ell = np.array([2.0, 2.5, 3.0, 2.2, 2.0, 2.8, 2.4]); sn = np.array([1e-1, 1e-1, 2e-1, 1e-1, 0.0, 1e-1, 3e-1])
+    with S.GPR(kernel="matern52", dtype="f32") as gp:
+        res = {}
+        for group in (4, 1):
+            res[group] = gp.fit_batch(Xb, yb, Xsb, ell, sn, concurrency=1, group=group)
+        r = res[4]
+        assert r["info"][4] > 0 and np.isinf(r["nlml"][4]) and np.all(np.delete(r["info"], 4) == 0)      # fit 4 = data set 1 with sn~ = 0
+        for i in range(F):
+            if i == 4:
+                continue
+            ref = O.fit_predict(Xb[i % B], yb[i % B], Xsb[i % B], ell[i], sn[i], kind="matern52", ref_idiom=False)
+            assert rel(r["mean"][i], ref["fmean"]) <= 1e-6 and rel(r["sigma_f"][i], ref["sigma_f"]) <= 1e-6, i
+            assert rel(r["var"][i], ref["fvar"]) <= 1e-5 and rel(r["nlml"][i], ref["nlml"]) <= 1e-5, i
+        ok = np.delete(np.arange(F), 4)
+        assert rel(res[4]["mean"][ok], res[1]["mean"][ok]) <= 1e-9 and rel(res[4]["nlml"][ok], res[1]["nlml"][ok]) <= 1e-9   # lockstep == one at a time
+        gp.fit(Xb[0], yb[0], ell[0], sn[0], Xs=Xsb[0])       # the single-fit state still works after a batch
+        mu, _ = gp.predict(Xsb[0])
+        assert rel(mu, r["mean"][0]) <= 1e-9
+
+
 # ---- 8f-2: the feature pipeline's tau() on the device -----------------------------------------------------------------------
 @pytest.mark.parametrize("case", ["a", "b", "c", "d"])
 def test_complex_networks_tau_on_the_device(S, case):
