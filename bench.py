@@ -280,7 +280,10 @@ def main():
     gp.close()
 
     if rank == 0 and world == 1 and not args.no_extras:
-        out["other_configs"] = other_configs(local)
+        try:
+            out["other_configs"] = other_configs(local)
+        except Exception as e:                   # untimed extras must never cost the metric line
+            out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, len(my_years), r, local)
