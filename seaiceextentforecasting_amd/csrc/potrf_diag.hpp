@@ -2,13 +2,15 @@
 // factor one 128x128 SPD block in LDS, write L11 back, then invert it in place and write inv(L11) to the
 // workspace so that the panel solve  L21 = A21 inv(L11)^T  is a plain MFMA GEMM.
 //
-// One 256-thread workgroup (the step is a latency chain, not throughput work).  The block lives in LDS
+// One 512-thread workgroup (the step is a latency chain, not throughput work).  The block lives in LDS
 // ([128][130] doubles: pitch 130 keeps the 8-byte MFMA fragment reads conflict free).  It is processed in
 // 16-column steps:
 //   B1  16x16 diagonal factorisation by ONE wave, rows in registers, pivots broadcast with v_readlane
 //       (wavefront shuffles, no LDS round trips, no barriers inside the step);
 //   B2  16-wide triangular solve of the rows below, one thread per row, L11 broadcast from LDS;
-//   B3  rank-16 update of the remaining lower tiles on v_mfma_f64_16x16x4_f64.
+//   B3  rank-16 update of the remaining lower tiles on v_mfma_f64_16x16x4_f64 -- with look-ahead: wave 0 takes the next
+//       diagonal tile first and runs B1 of the next step while the other waves finish the update, so the serial pivot chain
+//       of step jb+1 hides the bulk of B3 of step jb.
 // Register budget: the kernel must stay at <= 128 VGPRs (121 now).  Its 8 waves then take 2 x 128 of a SIMD's 512
 // registers and fit beside ONE resident wave of the trailing-update kernel (256 VGPRs); a 220-VGPR build (measured with a
 // DPP row_newbcast pivot loop, 7 % faster on an idle GPU) has to wait for BOTH update workgroups of a CU to finish:
@@ -76,44 +78,83 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
   __syncthreads();
 
   // ---- factorisation, 8 steps of 16 columns ----
+  // B1: 16x16 Cholesky of the diagonal tile jb by ONE wave; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by
+  // v_rsq_f64 + Goldschmidt
+  auto factor16 = [&](int jb) {
+    T* Sjj = S + dblk(jb, jb);
+    T r[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      T dj = readlane_t(r[j], j);
+      if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
+        if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
+        dj = (T)1;
+      }
+      const T y0 = rsq_seed(dj);
+      T g = dj * y0, hh = (T)0.5 * y0;
+      T e = fma(-hh, g, (T)0.5);
+      g = fma(g, e, g); hh = fma(hh, e, hh);
+      e = fma(-hh, g, (T)0.5);
+      g = fma(g, e, g); hh = fma(hh, e, hh);
+      const T e2 = fma(-g, g, dj);
+      const T s = fma(e2, hh, g);      // sqrt(dj)
+      const T inv = hh + hh;           // 1/sqrt(dj)
+      const T lij = (lr == j) ? s : r[j] * inv;
+      r[j] = lij;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) {
+        const T lcj = readlane_t(lij, c);
+        r[c] = fma(-lij, lcj, r[c]);
+      }
+      if (lane == 0) dinv[jb * 16 + j] = inv;
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : (T)0;
+    }
+  };
+  // one 16x16 tile of the rank-16 update: C(ti, tj) -= L(ti, jb) L(tj, jb)^T  (two of them interleaved so that one's MFMA
+  // dependency chain hides behind the other's)
+  auto update_pair = [&](int jb, int t, bool two, int t2) {
+    int ti0 = 0, rem = t;
+    while (rem > ti0) { rem -= ti0 + 1; ++ti0; }
+    const int tj0 = rem;
+    int ti1 = 0; rem = two ? t2 : t;
+    while (rem > ti1) { rem -= ti1 + 1; ++ti1; }
+    const int tj1 = rem;
+    T* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
+    T* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
+    const T* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
+    const T* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
+    acc_t acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      acc0[r] = C0[N_::drow(lq, r) * BP + lr];
+      acc1[r] = C1[N_::drow(lq, r) * BP + lr];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const T a0 = -A0[lr * BP + kk * 4 + lq];
+      const T b0 = B0[lr * BP + kk * 4 + lq];
+      const T a1 = -A1[lr * BP + kk * 4 + lq];
+      const T b1 = B1[lr * BP + kk * 4 + lq];
+      acc0 = N_::mfma(a0, b0, acc0);
+      acc1 = N_::mfma(a1, b1, acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) C0[N_::drow(lq, r) * BP + lr] = acc0[r];
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) C1[N_::drow(lq, r) * BP + lr] = acc1[r];
+    }
+  };
+
+  if (wave == 0 && !(skip & 1)) factor16(0);
+  __syncthreads();
   for (int jb = 0; jb < 8; ++jb) {
     T* Sjj = S + dblk(jb, jb);
-    if (wave == 0 && !(skip & 1)) {
-      // B1: 16x16 Cholesky; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by v_rsq_f64 + Goldschmidt
-      T r[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        T dj = readlane_t(r[j], j);
-        if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
-          if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
-          dj = (T)1;
-        }
-        const T y0 = rsq_seed(dj);
-        T g = dj * y0, hh = (T)0.5 * y0;
-        T e = fma(-hh, g, (T)0.5);
-        g = fma(g, e, g); hh = fma(hh, e, hh);
-        e = fma(-hh, g, (T)0.5);
-        g = fma(g, e, g); hh = fma(hh, e, hh);
-        const T e2 = fma(-g, g, dj);
-        const T s = fma(e2, hh, g);      // sqrt(dj)
-        const T inv = hh + hh;           // 1/sqrt(dj)
-        const T lij = (lr == j) ? s : r[j] * inv;
-        r[j] = lij;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          const T lcj = readlane_t(lij, c);
-          r[c] = fma(-lij, lcj, r[c]);
-        }
-        if (lane == 0) dinv[jb * 16 + j] = inv;
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : (T)0;
-      }
-    }
-    __syncthreads();
     // B2: rows below: x L11^T = a   (one thread per row)
     const int nrows = DB - (jb * 16 + 16);
     if (tid < nrows && !(skip & 2)) {
@@ -132,43 +173,16 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
       for (int c = 0; c < 16; ++c) Sr[c] = x[c];
     }
     __syncthreads();
-    // B3: rank-16 update of the lower tiles of the trailing (7-jb)x(7-jb) block grid; two independent tiles per
-    // wave iteration so the MFMA dependency chain of one tile hides behind the other's
+    // B3 with look-ahead: wave 0 updates the NEXT diagonal tile (tile 0 of the trailing grid) and factors it straight away
+    // (B1 of step jb + 1, the serial pivot chain) while waves 1..7 apply the rank-16 update to all the other lower tiles of
+    // the trailing (7-jb)x(7-jb) block grid, two tiles per iteration.
     const int nb = 7 - jb;
     const int nt = nb * (nb + 1) / 2;
-    for (int t = wave; t < nt && !(skip & 4); t += 16) {
-      int ti0 = 0, rem = t;
-      while (rem > ti0) { rem -= ti0 + 1; ++ti0; }
-      const int tj0 = rem;
-      const bool two = (t + 8) < nt;
-      int ti1 = 0; rem = two ? t + 8 : t;
-      while (rem > ti1) { rem -= ti1 + 1; ++ti1; }
-      const int tj1 = rem;
-      T* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
-      T* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
-      const T* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
-      const T* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
-      acc_t acc0, acc1;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        acc0[r] = C0[N_::drow(lq, r) * BP + lr];
-        acc1[r] = C1[N_::drow(lq, r) * BP + lr];
-      }
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const T a0 = -A0[lr * BP + kk * 4 + lq];
-        const T b0 = B0[lr * BP + kk * 4 + lq];
-        const T a1 = -A1[lr * BP + kk * 4 + lq];
-        const T b1 = B1[lr * BP + kk * 4 + lq];
-        acc0 = N_::mfma(a0, b0, acc0);
-        acc1 = N_::mfma(a1, b1, acc1);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) C0[N_::drow(lq, r) * BP + lr] = acc0[r];
-      if (two) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) C1[N_::drow(lq, r) * BP + lr] = acc1[r];
-      }
+    if (wave == 0) {
+      if (nt > 0 && !(skip & 4)) update_pair(jb, 0, false, 0);
+      if (jb < 7 && !(skip & 1)) factor16(jb + 1);
+    } else if (!(skip & 4)) {
+      for (int t = wave; t < nt; t += 14) update_pair(jb, t, (t + 7) < nt, t + 7);
     }
     __syncthreads();
   }
