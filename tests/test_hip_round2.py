@@ -267,6 +267,31 @@ def test_mlii_gradient_at_multi_block_sizes(S, kind, n, d):
     assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= max(TOL_PRED, 1e-6 * float(np.exp(th[1])))
 
 
+@pytest.mark.parametrize("opt,val", [("xcd_chunks", 8), ("xcd_chunks", 5), ("update_wgs", 1), ("update_wgs", 37)])
+def test_tile_walk_options_only_move_tiles(S, opt, val):
+    """The XCD-chunked walk and the persistent-grid walk of the trailing update place tiles on different workgroups and
+    nothing else: factor and results bit-identical to the default walk, single fit (two streams) and lockstep batch."""
+    X, y, Xs = O.synthetic_problem(4100, 8, 5, m=1)
+    Ls = []
+    for v in (0, val):
+        with S.GPR(kernel="rbf", outer_blocks=2) as gp:
+            gp.set_option("small_tile_threshold", 0)          # every update through the LDS-DMA kernel, however few tiles
+            gp.set_option(opt, v)
+            gp.fit(X, y, np.sqrt(8.0), 1e-2, Xs=Xs)
+            Ls.append((gp.L_tilde_, gp.nlml_))
+    assert np.array_equal(Ls[0][0], Ls[1][0]) and Ls[0][1] == Ls[1][1]
+    n, d, B = 2100, 8, 10
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 70 + b, m=1)
+    res = []
+    for v in (0, val):
+        with S.GPR(kernel="rbf", outer_blocks=4) as gp:
+            gp.set_option(opt, v)
+            res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
+    assert all(np.array_equal(res[0][k], res[1][k]) for k in ("nlml", "mean", "var", "sigma_f"))
+
+
 def test_fp32_lockstep_batch_matches_oracle(S):
     """fp32 engine, batch path: the factorisations of a group run in lockstep (one build, one blocked Cholesky over all
     members), the refinement member by member.  Different data sets and hyper-parameters per member, a non-SPD member
