@@ -49,6 +49,7 @@ struct Slot {
   double* mt = nullptr; int cap_mt = 0;   // panel_mode 1: [cap_mt][MT_LD][MT_LD] pre-multiplied top blocks (see panel_strip_kernel)
   hipStream_t s_upd = nullptr, s_pan = nullptr;
   hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
+  hipEvent_t ev_group = nullptr;   // recorded on s_upd when a lockstep group has finished (head pipelining of the next group)
 };
 
 }  // namespace
@@ -135,6 +136,10 @@ struct sigp_handle {
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
+  int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
+                             // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
+  int opt_update_late = 0;   // with update_wgs: only the outer updates of the last `update_late` panels run persistent (0 = all outer updates)
+  bool persist_now = false;  // set by potrf_core around the outer trailing updates it wants persistent
   int opt_update_wgs = 0;    // > 0: trailing updates with more tiles than this run as a persistent grid of this many workgroups (slots left free
                              // for the panel stream's latency chain); 0: one workgroup per tile
   int opt_group = 8;         // fits factorised in lockstep per launch in the batch path
@@ -208,6 +213,7 @@ int slot_init(sigp_handle* h, Slot& s) {
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_pan, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_la, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&s.ev_group, hipEventDisableTiming));
   return SIGP_OK;
 }
 
@@ -256,6 +262,7 @@ void slot_free(Slot& s) {
   if (s.ev_pan) (void)hipEventDestroy(s.ev_pan);
   if (s.ev_la) (void)hipEventDestroy(s.ev_la);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  if (s.ev_group) (void)hipEventDestroy(s.ev_group);
   if (s.s_upd) (void)hipStreamDestroy(s.s_upd);
   if (s.s_pan) (void)hipStreamDestroy(s.s_pan);
   s = Slot();
@@ -340,7 +347,7 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
   static AttrOnce attr;
   HIPCHK(h, attr.set(h->device, (const void*)syrk128_kernel<T, SET>, SY_LDS_BYTES));
   const long total = (long)nt * std::max(1, g.batch);
-  if (may_persist && h->opt_update_wgs > 0 && g.patch == 0 && total > h->opt_update_wgs) {
+  if (may_persist && h->persist_now && h->opt_update_wgs > 0 && g.patch == 0 && total > h->opt_update_wgs) {
     GemmArgsT<T> gp = g;
     gp.ntile = nt;
     static AttrOnce attr_p;
@@ -377,7 +384,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
     if (h->opt_c_dma) g.dbg |= 128;
-    return launch_syrk128_t<T, false>(h, st, g, true);
+    return launch_syrk128_t<T, false>(h, st, g, true);   // tile-walk options (xcd_chunks, update_wgs when persist_now) apply here
   }
   if (nt >= h->opt_small_tiles) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes);
@@ -399,22 +406,23 @@ KParams make_kparams(int kernel_id, double ell, double sn, int ds) {
 }
 
 // push the first nb entries of s.kps_host to the device (stream-ordered; kps_host stays untouched until retire)
-int upload_kparams(sigp_handle* h, Slot& s, int nb) {
-  HIPCHK(h, hipMemcpyAsync(s.kps, s.kps_host, (size_t)nb * sizeof(KParams), hipMemcpyHostToDevice, s.s_upd));
+int upload_kparams(sigp_handle* h, Slot& s, int nb, hipStream_t st = nullptr) {
+  HIPCHK(h, hipMemcpyAsync(s.kps, s.kps_host, (size_t)nb * sizeof(KParams), hipMemcpyHostToDevice, st ? st : s.s_upd));
   return SIGP_OK;
 }
 
 // RBF / Matern build of K~ (lower) + ride rows for the nb lockstep members of slot s.  Member b uses data set
 // kps[b].ds: X + ds*strideX, y + ds*stridey, Xs + ds*strideXs.
 int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, const double* y, long stridey, const double* Xs,
-              long strideXs, long n, long d, long dp, long n_pad, long m) {
+              long strideXs, long n, long d, long dp, long n_pad, long m, hipStream_t stb = nullptr) {
   const long ld = n_pad;
-  ProfScope ps(h, s.s_upd, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
+  hipStream_t st = stb ? stb : s.s_upd;
+  ProfScope ps(h, st, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
   dim3 grid((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb);
-  hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, s.s_upd, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
+  hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
-  hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, s.s_upd, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
+  hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, st, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
                      (int)n_pad, (int)m, 1, s.mat + n_pad * ld, s.matStride, ld, s.kps, 1);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -424,7 +432,7 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
 // Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
 // GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
 template <typename Real>
-int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad) {
+int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad, bool head_on_panel = false) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
@@ -434,13 +442,17 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     int rcm = slot_ensure_mt(h, s, nb);
     if (rcm) return rcm;
   }
-  HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), s.s_upd));
   static AttrOnce diag_attr;
   HIPCHK(h, diag_attr.set(h->device, (const void*)potrf_diag_kernel<Real>, diag_lds));
   const bool la = h->opt_lookahead != 0;
   hipStream_t sp = la ? s.s_pan : s.s_upd;   // panel stream
   hipStream_t su = s.s_upd;
-  if (la) {   // panel stream starts after the build on the update stream
+  // head_on_panel (lockstep batches, head pipelining): the covariance build of this group was enqueued on the PANEL stream and
+  // the update stream starts with a wait for the previous group, so the build and the first panel run while the previous
+  // group is still updating; nothing of this group's head may then be ordered behind the update stream
+  const bool head = head_on_panel && la;
+  HIPCHK(h, hipMemsetAsync(s.info, 0, (size_t)nb * sizeof(int), head ? sp : su));
+  if (la && !head) {   // panel stream starts after the build on the update stream
     HIPCHK(h, hipEventRecord(s.ev_la, su));
     HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
   }
@@ -538,7 +550,13 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     return SIGP_OK;
   };
   auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
-    return update(st, SIGP_KC_SYRK128, J, Wc, J + Wc, c0, c1, R);
+    // persistent form (update_wgs): only for outer trailing updates, and with update_late only for the last panels, where the
+    // updates are small and the panel chain they share the chip with is what the step waits for
+    const int panels_left = (T - (J + Wc) + W - 1) / W;
+    h->persist_now = h->opt_update_wgs > 0 && (h->opt_update_late == 0 || panels_left <= h->opt_update_late);
+    const int rc_ = update(st, SIGP_KC_SYRK128, J, Wc, J + Wc, c0, c1, R);
+    h->persist_now = false;
+    return rc_;
   };
 
   int rc = panel(0, std::min(W, T));
@@ -607,8 +625,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   return SIGP_OK;
 }
 
-int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad) {
-  return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad);
+int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad, bool head_on_panel = false) {
+  return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad, head_on_panel);
 }
 
 // stand-alone pieces of potrf_core for the multi-GPU driver (one member; Mm / dinvp = the fp64 slot matrix or the fp32 engine's)
@@ -1111,6 +1129,8 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "pipeline_head")) { h->opt_pipeline_head = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 256) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
   if (!strcmp(name, "host_timing")) { h->opt_host_timing = (int)value; return SIGP_OK; }
@@ -1662,10 +1682,17 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     const long g0 = g * G;
     const int nb = (int)std::min<long>(G, count - g0);
     for (int b = 0; b < nb; ++b) s.kps_host[b] = make_kparams(kernel_id, ell[g0 + b], sn_tilde[g0 + b], (int)((first + g0 + b) % h->b_count));
-    if ((rc = upload_kparams(h, s, nb))) return rc;
-    if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m))) return rc;
-    if ((rc = potrf_slot(h, s, nb, n_pad))) return rc;
+    // head pipelining: with >= 2 slots, group g's covariance build and first panel go on its panel stream and run while
+    // group g-1 is still in its trailing updates (where the first panel of a group otherwise leaves the update engine idle:
+    // ~8 % of a step); its update stream waits for group g-1 to finish, so the bulk of two groups never competes
+    const bool head = h->opt_pipeline_head && nslots >= 2 && h->opt_lookahead && h->opt_schedule == 0;
+    if (head && g > 0) HIPCHK(h, hipStreamWaitEvent(s.s_upd, h->slots[(g - 1) % nslots].ev_group, 0));
+    hipStream_t sb = head ? s.s_pan : s.s_upd;
+    if ((rc = upload_kparams(h, s, nb, sb))) return rc;
+    if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m, sb))) return rc;
+    if ((rc = potrf_slot(h, s, nb, n_pad, head))) return rc;
     if ((rc = epilogue_slot(h, s, nb, n, n_pad, m))) return rc;
+    if (head) HIPCHK(h, hipEventRecord(s.ev_group, s.s_upd));
     inflight[k] = g;
     enq_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count();
   }
