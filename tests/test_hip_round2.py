@@ -387,6 +387,41 @@ def test_detrend_on_the_device_matches_reference(S):
     assert np.nanmax(np.abs(ds2["dt"] - z["detrend_op/dt"])) <= 1e-12 and np.nanmax(np.abs(ds2["trend"] - z["detrend_op/trend"])) <= 1e-12
 
 
+def test_two_handles_on_two_threads_are_independent(S):
+    """sigp.h: a handle is not thread-safe, DISTINCT handles are independent.  Two threads, each with its own handle (ctypes
+    releases the GIL inside the C calls), interleave fits of different kernels, sizes and batch / single paths; every result
+    against the oracle.  Also exercises the once-per-device kernel-attribute setup under contention."""
+    import threading
+    errors = []
+
+    def worker(seed, kind):
+        try:
+            rng = np.random.default_rng(seed)
+            with S.GPR(kernel=kind) as gp:
+                for it in range(6):
+                    n = int(rng.integers(200, 1500)); d = int(rng.integers(2, 9))
+                    X, y, Xs = O.synthetic_problem(n, d, 1000 * seed + it, m=2)
+                    ell, sn = (float(np.sqrt(d)), 1e-2) if kind != "netdiffusion" else (0.05, 1e-1)
+                    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+                    if kind != "netdiffusion" and it % 2:
+                        r = gp.fit_batch(X, y, Xs, [ell, ell], [sn, sn], concurrency=2, group=2)
+                        mu, var, nl = r["mean"][1], r["var"][1], r["nlml"][1]
+                    else:
+                        gp.fit(X, y, ell, sn, Xs=Xs)
+                        mu, var = gp.predict(Xs); nl = gp.nlml_
+                    assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= TOL_PRED and rel(nl, ref["nlml"]) <= 1e-9, (seed, it)
+        except Exception as e:      # noqa: BLE001 -- reported by the main thread
+            errors.append((seed, kind, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(1, "rbf")), threading.Thread(target=worker, args=(2, "matern52")),
+          threading.Thread(target=worker, args=(3, "netdiffusion"))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+
+
 # ---- RCCL at world = 1, and the launcher ---------------------------------------------------------------------------------
 _NCCL_WORKER = r'''
 import os, sys
