@@ -225,11 +225,16 @@ int sigp_profile_reset(sigp_handle* h);
  *   schedule [0]          0 right-looking outer panels, 1 left-looking (same factor bit for bit)
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
  *   panel_ll [0]          panels up to this width are factored left-looking inside
- *   group [8]             fits factorised in lockstep per launch (batch path)
+ *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps
- *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack return without a host sync (see sigp_dist_sync)
- *   pan_priority, diag_prio, syrk_v2, patch, reserve_cus, c_dma, host_timing   measurement switches */
+ *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack / _local_update return without a host sync (see sigp_dist_sync)
+ *   owner_only [0]        sigp_set_train does not allocate the n x n slot matrix (sigp_dist_local_*)
+ *   tile walks of the trailing update -- placement only, results bit-identical; all measured slower than the default and left off
+ *   (DESIGN.md section 7):  xcd_chunks [0] (P: 64-tile chunks of PxP patches per XCD), update_wgs [0] (persistent grid of this many
+ *   workgroups) with update_late [0] (only for the last k panels), pipeline_head [0] (two lockstep groups in flight: only the next
+ *   group's build + first panel overlap the current group), small_nt64 [0] (one wavefront per fit in sigp_small_run)
+ *   pan_priority, diag_prio, patch, reserve_cus, host_timing   measurement switches; c_dma, syrk_v2: libsigp_debug.so only */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus
