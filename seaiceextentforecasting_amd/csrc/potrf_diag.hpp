@@ -85,13 +85,16 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
     T r[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
+    // Branch-free: the 16 pivots are ONE basic block, so the scheduler can run the tail of pivot j's column updates under the
+    // rsq / Goldschmidt latency of pivot j+1 (a per-pivot `if` for the failure case cut the block and serialised them).
+    int bad = 0;          // first non-positive / NaN pivot of this tile (1-based), uniform
+    T myinv = (T)0;       // lane j keeps 1/L_jj
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       T dj = readlane_t(r[j], j);
-      if (!(dj > (T)0)) {   // non-positive or NaN pivot: LAPACK info = index of the failing pivot
-        if (lane == 0 && *info == 0) *info = pivot_base + jb * 16 + j + 1;
-        dj = (T)1;
-      }
+      const bool neg = !(dj > (T)0);
+      bad = (neg && bad == 0) ? j + 1 : bad;
+      dj = neg ? (T)1 : dj;
       const T y0 = rsq_seed(dj);
       T g = dj * y0, hh = (T)0.5 * y0;
       T e = fma(-hh, g, (T)0.5);
@@ -103,17 +106,20 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
       const T inv = hh + hh;           // 1/sqrt(dj)
       const T lij = (lr == j) ? s : r[j] * inv;
       r[j] = lij;
+      myinv = (lr == j) ? inv : myinv;
 #pragma unroll
       for (int c = j + 1; c < 16; ++c) {
         const T lcj = readlane_t(lij, c);
         r[c] = fma(-lij, lcj, r[c]);
       }
-      if (lane == 0) dinv[jb * 16 + j] = inv;
     }
     if (lane < 16) {
+      dinv[jb * 16 + lr] = myinv;
 #pragma unroll
       for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : (T)0;
     }
+    // LAPACK info = index of the first failing pivot
+    if (bad != 0 && lane == 0 && *info == 0) *info = pivot_base + jb * 16 + bad;
   };
   // one 16x16 tile of the rank-16 update: C(ti, tj) -= L(ti, jb) L(tj, jb)^T  (two of them interleaved so that one's MFMA
   // dependency chain hides behind the other's)
@@ -220,56 +226,53 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
   }
   __syncthreads();
 
-  // ---- blocked in-place inverse, last block column first:  X[ib][jb] = -(sum_p X[ib][p] L[p][jb]) X[jb][jb] ----
-  // wave w owns block row ib = jb+1+w (at most 7 rows -> one per wave)
-  for (int jb = 6; jb >= 0 && !(skip & 16); --jb) {
-    const int nb = 7 - jb;
-    const int ib = jb + 1 + wave;
-    acc_t acc, accb;
+  // ---- blocked in-place inverse by recursive doubling:  [L11 0; L21 L22]^-1 = [X11 0; -X22 (L21 X11)  X22] ----
+  // Level s (in 16x16 tiles, s = 1, 2, 4) joins the 8/(2s) pairs of finished s-tile inverse blocks: first P = L21 X11 (it
+  // overwrites L21, whose copy in global memory was written back above), then X21 = -X22 P; the 4s tiles of a level are
+  // dealt over the 8 waves (two per wave at s = 4).  3 levels x 4 barriers and dependency chains of at most 16 MFMAs,
+  // against 7 column steps x 2 barriers with chains of up to 28 in the column-by-column recurrence this replaces (9.7 us).
+  for (int sblk = 1; sblk < 8 && !(skip & 16); sblk *= 2) {
+    const int ntile = 4 * sblk, s2 = sblk * sblk;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { acc[r] = (T)0; accb[r] = (T)0; }
-    if (wave < nb) {
-      // two interleaved accumulation chains (even / odd p)
-      for (int p = jb + 1; p <= ib; p += 2) {
-        const bool hasb = (p + 1) <= ib;
-        const int pb = hasb ? p + 1 : p;
-        const T* Xa = S + dblk(ib, p), *La = S + dblk(p, jb);
-        const T* Xb = S + dblk(ib, pb), *Lb = S + dblk(pb, jb);
+    for (int phase = 0; phase < 2; ++phase) {
+      acc_t res[2];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          const T a = Xa[lr * BP + kk * 4 + lq];      // X[ib][p] (row lr, k)
-          const T b = La[(kk * 4 + lq) * BP + lr];    // L[p][jb] (k, col lr)
-          T a2 = Xb[lr * BP + kk * 4 + lq];
-          const T b2 = Lb[(kk * 4 + lq) * BP + lr];
-          if (!hasb) a2 = (T)0;
-          acc = N_::mfma(a, b, acc);
-          accb = N_::mfma(a2, b2, accb);
+      for (int q = 0; q < 2; ++q) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) res[q][r] = (T)0;
+        const int t = wave + 8 * q;
+        if (t < ntile) {
+          const int pair = t / s2, w = t - pair * s2, i = w / sblk, j = w - i * sblk;
+          const int b0 = pair * 2 * sblk;
+          // phase 0:  P(i, j)   = sum_{k = j}^{s-1} L21(i, k) X11(k, j)      (X11 lower triangular)
+          // phase 1:  X21(i, j) = -sum_{k = 0}^{i}  X22(i, k) P(k, j)        (X22 lower triangular)
+          const int k0 = phase == 0 ? j : 0, k1 = phase == 0 ? sblk - 1 : i;
+          for (int k = k0; k <= k1; ++k) {
+            const T* A_ = phase == 0 ? S + dblk(b0 + sblk + i, b0 + k) : S + dblk(b0 + sblk + i, b0 + sblk + k);
+            const T* B_ = phase == 0 ? S + dblk(b0 + k, b0 + j) : S + dblk(b0 + sblk + k, b0 + j);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              T a_ = A_[lr * BP + kk * 4 + lq];           // (row lr, k)
+              const T b_ = B_[(kk * 4 + lq) * BP + lr];   // (k, col lr)
+              if (phase == 1) a_ = -a_;
+              res[q] = N_::mfma(a_, b_, res[q]);
+            }
+          }
         }
       }
-      acc += accb;
-    }
-    __syncthreads();   // every read of the original L[.][jb] is done
-    if (wave < nb) {
-      // park T in the (wave-private) destination block so it can be re-read in A-operand layout
-      T* D = S + dblk(ib, jb);
-      const T* Xjj = S + dblk(jb, jb);
+      __syncthreads();   // every read of the blocks about to be overwritten (L21, then P) is done
 #pragma unroll
-      for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = acc[r];
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("" ::: "memory");
-      acc_t u;
+      for (int q = 0; q < 2; ++q) {
+        const int t = wave + 8 * q;
+        if (t < ntile) {
+          const int pair = t / s2, w = t - pair * s2, i = w / sblk, j = w - i * sblk;
+          T* D = S + dblk(pair * 2 * sblk + sblk + i, pair * 2 * sblk + j);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) u[r] = (T)0;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const T a = -D[lr * BP + kk * 4 + lq];
-        const T b = Xjj[(kk * 4 + lq) * BP + lr];
-        u = N_::mfma(a, b, u);
+          for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = res[q][r];
+        }
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = u[r];
+      __syncthreads();
     }
-    __syncthreads();
   }
 
   // ---- write inv(L11) (lower triangle) ----
