@@ -2,7 +2,7 @@
 """Time ONE large fit sharded over the ranks of a node (BASELINE configs[3]: n=16384, d=16, fp64 RBF).
 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 tools/dist_bench.py \
-        [--n 16384] [--d 16] [--outer 8] [--reps 3] [--no-lookahead]
+        [--n 16384] [--d 16] [--outer 8] [--reps 3] [--no-lookahead] [--owner-only]
 
 Backend "nccl" (RCCL over xGMI) when every rank has its own GPU; SIGP_BENCH_BACKEND=gloo lets several ranks share one
 GPU to rehearse the protocol (timings are then meaningless for scaling: the ranks time-share the card).
@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"], help="f32: configs[4] (use --n 32768 --d 32 --kernel matern52 --sn 0.1)")
     ap.add_argument("--kernel", default="rbf", choices=["rbf", "matern52"])
     ap.add_argument("--sn", type=float, default=1e-2)
+    ap.add_argument("--owner-only", action="store_true", help="owner-only storage (sigp_dist_local_*): per-rank matrix bytes ~ 1/world")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
@@ -50,7 +51,8 @@ def main():
         Xs = Xs[:1]
     ell, sn = np.sqrt(d), args.sn
     times = []
-    with DistributedGPR(args.kernel, rank, world, dist, device=local, outer_blocks=args.outer, lookahead=not args.no_lookahead, dtype=args.dtype) as dg:
+    with DistributedGPR(args.kernel, rank, world, dist, device=local, outer_blocks=args.outer, lookahead=not args.no_lookahead, dtype=args.dtype,
+                        owner_only=args.owner_only) as dg:
         for r in range(args.reps + 1):
             if dist.is_initialized():
                 dist.barrier()
@@ -66,7 +68,7 @@ def main():
             if r > 0:
                 times.append(t)
         mu, var = dg.predict(Xs)
-        sf, nl = dg.sigma_f_, dg.nlml_
+        sf, nl, mbytes = dg.sigma_f_, dg.nlml_, dg.matrix_bytes_
     single = None
     if rank == 0:      # the same fit through the single-GPU entry point, for reference
         with GPR(kernel=args.kernel, device=local, outer_blocks=args.outer, dtype=args.dtype) as gp:
@@ -81,7 +83,7 @@ def main():
                           "backend": backend if world > 1 else "none", "lookahead": not args.no_lookahead, "ms_per_fit": [round(1e3 * t, 2) for t in times],
                           "fits_per_s": 1.0 / best, "tflops": flops / best / 1e12, "single_gpu_entry_ms": round(1e3 * single, 2),
                           "mean_rel_vs_single": float(abs(mu[0] - mu1[0]) / abs(mu1[0])), "var_rel_vs_single": float(abs(var[0] - var1[0]) / abs(var1[0])),
-                          "sigma_f": sf, "nlml": nl}))
+                          "sigma_f": sf, "nlml": nl, "owner_only": args.owner_only, "matrix_bytes_rank0": mbytes}))
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
