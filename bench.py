@@ -12,7 +12,9 @@ N > 1 (one process per GPU, RCCL for the barrier / max-reduce only -- independen
   --scaling strong the fixed job (steps x 40 fits) is dealt round-robin over the ranks (a rank's lockstep groups then mix
                    years and grid points)
 `python bench.py --gpus N` without a torchrun environment starts the N ranks itself (a `torch.distributed.run` child,
-spawned before this process touches the GPU); under torchrun WORLD_SIZE must equal --gpus.
+spawned before this process touches the GPU); under torchrun WORLD_SIZE must equal --gpus.  (torchrun's own parser claims
+abbreviations of ITS options even after the script name, e.g. --n / --d / --no: pass such flags through the self-spawning
+form, or as a JSON list in SIGP_BENCH_ARGV with no flags on the command line; --gpus / --steps / --warmup are unaffected.)
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--grid smoke|full] [--scaling weak|strong] [--n 8192] [--d 8]
 """
