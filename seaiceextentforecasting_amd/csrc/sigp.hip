@@ -1782,10 +1782,11 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
     g.r0 = 0; g.r1 = T; g.c0 = 0; g.c1 = T; g.lower = 1; g.ktri = 1;
     if ((rc = launch_syrk128_t<double, true>(h, st, g))) return rc;
   }
-  // A~ = L~^-T z by the backward block solve of the ride row
-  HIPCHK(h, hipMemsetAsync(h->scratchZ, 0, (size_t)RIDE * n_pad * sizeof(double), st));
-  HIPCHK(h, hipMemcpyAsync(h->scratchZ, s.mat + n_pad * ld, (size_t)n_pad * sizeof(double), hipMemcpyDeviceToDevice, st));
-  if ((rc = solve_rows_backward(h, s, h->scratchZ, n_pad))) return rc;
+  // A~ = L~^-T z = U z: one skinny product with the upper-triangular U (one wave per row, k from the diagonal) instead of a
+  // backward block solve of 2 launches per 128 columns
+  hipLaunchKernelGGL(rowdot_kernel<double>, dim3((unsigned)((n_pad + 3) / 4)), dim3(256), 0, st, (const double*)h->gU, ld, (int)n_pad, (int)n_pad, 2,
+                     (const double*)(s.mat + n_pad * ld), ld, h->scratchZ, ld, 1, 0);
+  HIPCHK(h, hipGetLastError());
   // dK~_1 (full symmetric): the reference's X (M Sigma~) X^T, or d k~/d log l for RBF / Matern
   if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
     if ((rc = build_xsxt(h, MSigma, ldsigma, h->gD))) return rc;
