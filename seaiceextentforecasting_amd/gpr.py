@@ -343,6 +343,16 @@ class GPR:
         self._batch_m = m
         return self.run_batch(0, F, ell, sn, concurrency, group)
 
+    def predict_batch(self, X, y, Xs, ell, sn_tilde, **kw):
+        """(mean [F, m], var [F, m]) of a batch of independent fits at their test points -- the per-(region, year) outputs
+        ``fmean`` / ``fvar`` of the retro loop (September1st_retro.py:236-242).  The test points ride along each factorisation,
+        so this IS ``fit_batch``; it exists for callers that only want the predictions."""
+        r = self.fit_batch(X, y, Xs, ell, sn_tilde, **kw)
+        if np.any(r["info"] != 0):
+            bad = int(np.flatnonzero(r["info"])[0])
+            raise LinAlgError("Matrix is not positive definite (fit %d, pivot %d)" % (bad, r["info"][bad]), int(r["info"][bad]))
+        return r["mean"], r["var"]
+
     def _fit_batch_netdiffusion(self, X, y, Xs, ell, sn_tilde, M=None):
         from .smallbatch import SmallBatch, NMAX, MMAX
         if isinstance(X, np.ndarray) and X.ndim == 2:

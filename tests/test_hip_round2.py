@@ -91,6 +91,11 @@ def test_small_batch_isolates_a_non_spd_fit(S):
     with pytest.raises(ValueError):
         with S.GPR(kernel="netdiffusion") as gp:
             S.SmallBatch(gp).add_dataset(np.zeros((129, 3)), np.zeros(129))
+    with S.GPR(kernel="netdiffusion") as gp:           # predict_batch: predictions only, LinAlgError where the reference would raise
+        mu, var = gp.predict_batch([X, X], [y, 2 * y], [Xs, Xs], [0.05, 0.05], [1e-2, 1e-2])
+        assert rel(mu[0], ref["fmean"]) <= TOL_PRED and rel(mu[1], 2 * ref["fmean"]) <= TOL_PRED and rel(var[0], ref["fvar"]) <= TOL_PRED
+        with pytest.raises(np.linalg.LinAlgError):
+            gp.predict_batch([X, Xbad], [y, y], [Xs, Xs], [0.05, 0.05], [1e-2, 0.0])
 
 
 def test_golden_scripts_through_the_batched_engine(S, golden):
