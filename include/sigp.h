@@ -134,6 +134,11 @@ int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, cons
 int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, int64_t lds, double r_crit, double* R, int64_t ldr,
                   double* sum_out, double* count_out);
 
+/* ComplexNetworks.Network.intra_links (ComplexNetworks.py:298-309): the per-area anomaly series that become the GP's features.
+ * data [P][T] pixel-major, weight [P] (sqrt(cell area) or sqrt(cos lat)), label [P] = area index 0..A-1 of the pixel or -1;
+ * out [A][T] = sum over the area's pixels of data * weight (NaN products as 0), pixels added in ascending order. */
+int sigp_area_sums(sigp_handle* h, const double* data, int64_t P, int64_t T, const double* weight, const int32_t* label, int64_t A, double* out);
+
 /* The step before the feature pipeline: detrend() of north/June1st.py:179-194 (one cut: cut_len = {T}) and of the retro
  * scripts (north/retrospective_forecasts/June1st_retro.py:178-195: one detrended cube per cut-off year) in ONE launch.
  * data [P][T] pixel-major anomaly series; cut c removes the least-squares line (scipy.stats.linregress semantics, NaN propagating)

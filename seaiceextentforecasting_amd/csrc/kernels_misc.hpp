@@ -440,6 +440,23 @@ __global__ __launch_bounds__(256) void corr_threshold_kernel(double* __restrict_
   if (threadIdx.x == 0) { part[2 * i] = s; part[2 * i + 1] = c; }
 }
 
+// ---- ComplexNetworks intra_links(): per-area anomaly series (behaviour of ComplexNetworks.py:298-309) -------------------
+// out[a][t] = sum over the pixels p with label[p] == a of data[p][t] * weight[p], NaN products counted as 0, pixels added in
+// ascending p (row-major) order -- the same additions in the same order as the host restatement, so results are bit-identical.
+// One thread per (area, time step); the label scan is shared by the T threads of an area through L1/L2.
+__global__ void area_sums_kernel(const double* __restrict__ data, const double* __restrict__ weight, const int* __restrict__ label, int P, int T,
+                                 int A, double* __restrict__ out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x, a = blockIdx.y;
+  if (t >= T || a >= A) return;
+  double acc = 0.0;
+  for (int p = 0; p < P; ++p) {
+    if (label[p] != a) continue;
+    const double v = data[(long)p * T + t] * weight[p];
+    acc += (v != v) ? 0.0 : v;
+  }
+  out[(long)a * T + t] = acc;
+}
+
 // ---- per-pixel linear detrending, every cut-off year in one launch (behaviour of north/June1st.py:179-194 and
 // north/retrospective_forecasts/June1st_retro.py:178-195: scipy.stats.linregress per pixel in a Python double loop) --------
 // data [P][T]; cut c uses the first ncut[c] time steps.  dt_out: cut c's detrended series at dt_off[c] + p*ncut[c]; trend_out

@@ -1956,6 +1956,26 @@ int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, in
   return SIGP_OK;
 }
 
+// ---- intra_links(): the per-area anomaly series that become the GP's features ----------------------------------------------
+int sigp_area_sums(sigp_handle* h, const double* data, int64_t P, int64_t T, const double* weight, const int32_t* label, int64_t A, double* out) {
+  if (!h || !data || !weight || !label || !out || P < 1 || T < 1 || A < 1) return fail(h, SIGP_BAD_ARG, "area_sums: bad argument");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipStream_t st = h->slots[0].s_upd;
+  int rc;
+  const long lab_dbl = (P + 1) / 2;                                  // int32 labels, in doubles
+  if ((rc = ensure(h, &h->stage, &h->cap_stage, P * T + P + lab_dbl + A * T))) return rc;
+  double* d_data = h->stage; double* d_w = d_data + P * T; int* d_lab = (int*)(d_w + P); double* d_out = d_w + P + lab_dbl;
+  HIPCHK(h, hipMemcpyAsync(d_data, data, (size_t)(P * T) * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_w, weight, (size_t)P * sizeof(double), hipMemcpyHostToDevice, st));
+  HIPCHK(h, hipMemcpyAsync(d_lab, label, (size_t)P * sizeof(int), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(area_sums_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)A), dim3(64), 0, st, (const double*)d_data, (const double*)d_w, (const int*)d_lab, (int)P,
+                     (int)T, (int)A, d_out);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)(A * T) * sizeof(double), hipMemcpyDeviceToHost, st));
+  HIPCHK(h, hipStreamSynchronize(st));
+  return SIGP_OK;
+}
+
 // ---- detrend(): per-pixel least-squares line removal for every cut-off year in one launch --------------------------------
 int sigp_detrend(sigp_handle* h, const double* data, int64_t P, int64_t T, int64_t ncuts, const int64_t* cut_len, double* dt_out, double* trend_out) {
   if (!h || !data || P < 1 || T < 2 || ncuts < 1 || !cut_len || !dt_out || !trend_out) return fail(h, SIGP_BAD_ARG, "detrend: bad argument");

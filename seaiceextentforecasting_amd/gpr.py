@@ -457,6 +457,16 @@ class GPR:
         with np.errstate(invalid="ignore", divide="ignore"):
             return R, np.float64(s.value) / np.float64(c.value)
 
+    def area_sums(self, data, weight, label, nareas):
+        """Per-area weighted sums of ``data`` [X, Y, T] (networks.Network.intra_links(engine=gp)): out [nareas, T]."""
+        data = L.f64(data, 3)
+        X, Y, T = data.shape
+        w = L.f64(np.broadcast_to(weight, (X, Y)), 2)
+        lab = np.ascontiguousarray(label, dtype=np.int32).reshape(X * Y)
+        out = np.empty((int(nareas), T))
+        self._check(self._lib.sigp_area_sums(self._h, L.ptr(data), X * Y, T, L.ptr(w), L.iptr(lab), int(nareas), L.ptr(out)), "area_sums")
+        return out
+
     def detrend_cuts(self, data, cut_lens):
         """Per-pixel line removal of ``data`` [X, Y, T] over its first ``cut_lens[c]`` steps, every cut in one launch
         (callers.detrend(engine=gp)).  Returns ([dt [X, Y, n_c] ...], [trend [X, Y, 2] ...])."""

@@ -224,10 +224,12 @@ class Network:
         self.unavail = unavail_list
 
     # ---- area series and links (behaviour of ComplexNetworks.py:283-326) -----------------------------------
-    def intra_links(self, area=None, lat=None):
+    def intra_links(self, area=None, lat=None, engine=None):
         """Per-area anomaly series (the GP's features): the sum over an area's cells of the cell series weighted by
         sqrt(cell area) (or sqrt(cos lat) on a lat-lon grid); ``links`` = covariance between area series (0 on the
-        diagonal), ``strength`` = sum of |links|, painted onto the cells as ``strengthmap``."""
+        diagonal), ``strength`` = sum of |links|, painted onto the cells as ``strengthmap``.
+        ``engine``: a ``GPR`` handle -- the area sums are then formed on the GPU (``sigp_area_sums``, same additions in the
+        same order: bit-identical)."""
         if lat is not None:
             weight = np.sqrt(np.cos(np.radians(lat)))
         elif area is not None:
@@ -236,7 +238,13 @@ class Network:
             weight = np.ones((self.dimX, self.dimY))
         ids = list(self.V)
         series = np.zeros((len(ids), self.dimT))
-        for row, A in enumerate(ids):
+        if engine is not None and ids:
+            label = np.full((self.dimX, self.dimY), -1, dtype=np.int32)
+            for row, A in enumerate(ids):
+                cells = np.asarray(self.V[A], dtype=np.int64)
+                label[cells[:, 0], cells[:, 1]] = row
+            series = engine.area_sums(self.data, weight, label, len(ids))
+        for row, A in enumerate(ids if engine is None else []):
             # unique cells in row-major order, accumulated one after the other: the same additions in the same order as
             # a NaN-padded cube reduced over its two leading axes, without building that cube per area
             flat = np.unique([c[0] * self.dimY + c[1] for c in self.V[A]])

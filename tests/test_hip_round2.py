@@ -330,7 +330,8 @@ def test_fp32_lockstep_batch_matches_oracle(S):
 @pytest.mark.parametrize("case", ["a", "b", "c", "d"])
 def test_complex_networks_tau_on_the_device(S, case):
     """networks.Network.tau(engine=gp): correlation matrix as one fp64 MFMA product + fused threshold reduction
-    (sigp_corr_tau) against the reference module's goldens: tau <= 1e-13, the areas V identical, anomaly series <= 1e-13."""
+    (sigp_corr_tau) against the reference module's goldens: tau <= 1e-13, the areas V identical; intra_links(engine=gp)
+    (sigp_area_sums): anomaly series bit-identical to the goldens (same additions in the same order)."""
     import seaiceextentforecasting_amd.networks as NW
     z = np.load(os.path.join(ROOT, "tests", "golden", "networks_%s.npz" % case), allow_pickle=False)
     data, aux, latlon = z["data"], z["aux"], bool(int(z["latlon"]))
@@ -339,21 +340,23 @@ def test_complex_networks_tau_on_the_device(S, case):
     with S.GPR(kernel="rbf") as gp:
         net = NW.Network(data=data.copy())
         NW.Network.tau(net, 0.01, engine=gp)
-    assert abs(net.tau - float(z["tau"])) <= 1e-13 * abs(float(z["tau"]))
-    off = ~np.eye(host._R.shape[0], dtype=bool)
-    assert np.array_equal(np.isnan(net._R), np.isnan(host._R))
-    assert np.nanmax(np.abs(net._R[off] - host._R[off])) <= 1e-13
-    NW.Network.area_level(net, latlon_grid=latlon)
-    ids = [int(i) for i in z["area_ids"]]
-    assert list(net.V.keys()) == ids
+        assert abs(net.tau - float(z["tau"])) <= 1e-13 * abs(float(z["tau"]))
+        off = ~np.eye(host._R.shape[0], dtype=bool)
+        assert np.array_equal(np.isnan(net._R), np.isnan(host._R))
+        assert np.nanmax(np.abs(net._R[off] - host._R[off])) <= 1e-13
+        NW.Network.area_level(net, latlon_grid=latlon)
+        ids = [int(i) for i in z["area_ids"]]
+        assert list(net.V.keys()) == ids
+        for k in ids:
+            assert np.array_equal(np.array(net.V[k], dtype=np.int64), z["V/%d" % k]), k
+        if latlon:
+            NW.Network.intra_links(net, lat=aux, engine=gp)
+        else:
+            NW.Network.intra_links(net, area=aux, engine=gp)
     for k in ids:
-        assert np.array_equal(np.array(net.V[k], dtype=np.int64), z["V/%d" % k]), k
-    if latlon:
-        NW.Network.intra_links(net, lat=aux)
-    else:
-        NW.Network.intra_links(net, area=aux)
-    for k in ids:
-        assert np.max(np.abs(net.anomaly[k] - z["anomaly/%d" % k])) <= 1e-13 * max(1.0, np.max(np.abs(z["anomaly/%d" % k])))
+        assert np.array_equal(net.anomaly[k], z["anomaly/%d" % k]), k
+        assert np.allclose(net.links[k], z["links/%d" % k], rtol=1e-13, atol=1e-13)
+    assert np.array_equal(np.isnan(net.strengthmap), np.isnan(z["strengthmap"]))
 
 
 def test_tau_on_the_device_realistic_grid(S):
