@@ -231,7 +231,7 @@ int sigp_profile_reset(sigp_handle* h);
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
  *   panel_ll [0]          panels up to this width are factored left-looking inside
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
- *   small_tile_threshold [320], trsm128_threshold [256]   tile-shape switches by tile count
+ *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps
  *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack / _local_update return without a host sync (see sigp_dist_sync)
  *   owner_only [0]        sigp_set_train does not allocate the n x n slot matrix (sigp_dist_local_*)

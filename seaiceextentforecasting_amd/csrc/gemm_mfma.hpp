@@ -242,32 +242,36 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   const int bkr = tid / BT_TPR, bcp = (tid % BT_TPR) * NE;
   constexpr int BT_RPP = 256 / BT_TPR;                             // k-rows per pass
 
-  v16_t va[PA], vb[PB];
-#define SIGP_GLOAD(k0)                                                                         \
+  // Register prefetch depth: small tiles (the latency-chain launches: panel solves, inner updates, block solves) keep PD K-slices
+  // in flight in registers, so a slice costs max(MFMA time, global latency / PD) instead of a whole global-load latency; the LDS
+  // image stays double-buffered (a slice goes to LDS one step before it is used).  The 128x128 tile has no registers to spare.
+  constexpr int PD = (TM * TN <= 64 * 64) ? 4 : 1;
+  v16_t va[PD][PA], vb[PD][PB];
+#define SIGP_GLOAD(k0, q)                                                                      \
   {                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PA; ++p)                                             \
-        va[p] = *(const v16_t*)(Ag + (long)(arow + 32 * p) * g.lda + (k0) + acp);              \
+        va[q][p] = *(const v16_t*)(Ag + (long)(arow + 32 * p) * g.lda + (k0) + acp);           \
     if (BT) {                                                                                  \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          vb[p] = *(const v16_t*)(Bg + (long)((k0) + bkr + BT_RPP * p) * g.ldb + bcp);         \
+          vb[q][p] = *(const v16_t*)(Bg + (long)((k0) + bkr + BT_RPP * p) * g.ldb + bcp);      \
     } else {                                                                                   \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          vb[p] = *(const v16_t*)(Bg + (long)(arow + 32 * p) * g.ldb + (k0) + acp);            \
+          vb[q][p] = *(const v16_t*)(Bg + (long)(arow + 32 * p) * g.ldb + (k0) + acp);         \
     }                                                                                          \
   }
-#define SIGP_SSTORE(buf)                                                                       \
+#define SIGP_SSTORE(buf, q)                                                                    \
   {                                                                                            \
     _Pragma("unroll") for (int p = 0; p < PA; ++p) {                                           \
-      v16_t t = va[p];                                                                         \
+      v16_t t = va[q][p];                                                                      \
       if (MODE != GEMM_SET) t = -t;                                                            \
       *(v16_t*)(As + ((buf) * TM + arow + 32 * p) * LDPe + acp) = t;                           \
     }                                                                                          \
     if (BT) {                                                                                  \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          *(v16_t*)(Bs + ((buf) * KTe + bkr + BT_RPP * p) * BTP + bcp) = vb[p];                \
+          *(v16_t*)(Bs + ((buf) * KTe + bkr + BT_RPP * p) * BTP + bcp) = vb[q][p];             \
     } else {                                                                                   \
       _Pragma("unroll") for (int p = 0; p < PB; ++p)                                           \
-          *(v16_t*)(Bs + ((buf) * TN + arow + 32 * p) * LDPe + acp) = vb[p];                   \
+          *(v16_t*)(Bs + ((buf) * TN + arow + 32 * p) * LDPe + acp) = vb[q][p];                \
     }                                                                                          \
   }
 
@@ -276,28 +280,37 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   if (g.ktri == 2) Kspan = min(Kspan, (bj + 1) * TN);
   const int nst = Kspan / KTe;
   const int dbg = g.dbg & DBG_MASK;
-  SIGP_GLOAD(0);
-  SIGP_SSTORE(0);
+#pragma unroll
+  for (int q = 0; q < PD; ++q)
+    if (q < nst) SIGP_GLOAD(q * KTe, q);
+  SIGP_SSTORE(0, 0);
   __syncthreads();
-  for (int s = 0; s < nst; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nst && !(dbg & 1)) SIGP_GLOAD((s + 1) * KTe);
-    const T* Ab = As + (buf * TM + wm * WTM + lr) * LDPe + lq;
-    const T* Bb = BT ? Bs + (buf * KTe + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDPe + lq;
+  // invariant at step s: LDS buffer s&1 holds slice s, register set (s+j) % PD holds slice s+j for 1 <= j < PD, set s % PD is free
+  for (int s0 = 0; s0 < nst; s0 += PD) {
 #pragma unroll
-    for (int kk = 0; kk < KTe / 4; ++kk) {
-      T a[FM], b[FN];
+    for (int q = 0; q < PD; ++q) {
+      const int s = s0 + q;
+      if (s < nst) {
+        const int buf = s & 1;
+        if (s + PD < nst && !(dbg & 1)) SIGP_GLOAD((s + PD) * KTe, q);
+        const T* Ab = As + (buf * TM + wm * WTM + lr) * LDPe + lq;
+        const T* Bb = BT ? Bs + (buf * KTe + lq) * BTP + wn * WTN + lr : Bs + (buf * TN + wn * WTN + lr) * LDPe + lq;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) a[i] = Ab[i * 16 * LDPe + kk * 4];
+        for (int kk = 0; kk < KTe / 4; ++kk) {
+          T a[FM], b[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) b[j] = BT ? Bb[kk * 4 * BTP + j * 16] : Bb[j * 16 * LDPe + kk * 4];
+          for (int i = 0; i < FM; ++i) a[i] = Ab[i * 16 * LDPe + kk * 4];
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+          for (int j = 0; j < FN; ++j) b[j] = BT ? Bb[kk * 4 * BTP + j * 16] : Bb[j * 16 * LDPe + kk * 4];
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = N_::mfma(a[i], b[j], acc[i][j]);
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = N_::mfma(a[i], b[j], acc[i][j]);
+        }
+        if (s + 1 < nst && !(dbg & 2)) SIGP_SSTORE(buf ^ 1, (q + 1) % PD);
+        if (!(dbg & 4)) __syncthreads();
+      }
     }
-    if (s + 1 < nst && !(dbg & 2)) SIGP_SSTORE(buf ^ 1);
-    if (!(dbg & 4)) __syncthreads();
   }
 #undef SIGP_GLOAD
 #undef SIGP_SSTORE

@@ -123,6 +123,7 @@ struct sigp_handle {
   int opt_outer = 8;       // outer panel width in 128-blocks (K = 1024 trailing updates; single fits: 8.7 vs 9.0 ms at n = 8192, 34.6 vs 42.1 ms at n = 16384 against 2)
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
+  int opt_tiny_tiles = 256;  // use 32x32 tiles when the 64-tile count (x members) is at most this (latency-bound single fits)
   int opt_pan_priority = 1;  // panel streams at high priority
   int opt_panel_ll = 0;      // panels up to this width are factored left-looking (0 = binary recursion only)
   int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
@@ -391,6 +392,10 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
     return launch_gemm_cfg<T, 128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
   }
   ProfScope ps(h, st, SIGP_KC_UPDATE_SMALL, flops, bytes);
+  if (nt * 4 <= h->opt_tiny_tiles) {            // so few 64-tiles that most SIMDs would idle: 32x32 tiles, a quarter of the MFMA chain per wave
+    g.r0 *= 4; g.r1 *= 4; g.c0 *= 4; g.c1 *= 4;
+    return launch_gemm_cfg<T, 32, 32, 2, 2, GEMM_SUB, false>(h, st, g);
+  }
   g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
   return launch_gemm_cfg<T, 64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
 }
@@ -1149,6 +1154,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     }
     return SIGP_OK;
   }
+  if (!strcmp(name, "tiny_tile_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_tiny_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "small_tile_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_small_tiles = (int)value; return SIGP_OK; }
   return fail(h, SIGP_BAD_ARG, "unknown option %s", name);
 }
