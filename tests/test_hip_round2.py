@@ -48,6 +48,7 @@ def test_small_batch_matches_oracle_on_ragged_sets(S, expm):
     sets = _ragged_sets(rng, 14)
     sets.append((rng.standard_normal((128, 60)), rng.standard_normal(128), rng.standard_normal((8, 60))))
     sets.append((rng.standard_normal((2, 1)), rng.standard_normal(2), rng.standard_normal((1, 1))))
+    sets.append((rng.standard_normal((1, 3)), rng.standard_normal(1), rng.standard_normal((2, 3))))           # a single training row: M = 0, K~ = x x^T + sn~
     sets.append((rng.standard_normal((45, 200)), rng.standard_normal(45), rng.standard_normal((1, 200))))     # reference size
     with S.GPR(kernel="netdiffusion") as gp:
         sb = S.SmallBatch(gp)
