@@ -99,6 +99,27 @@ def test_small_batch_isolates_a_non_spd_fit(S):
             gp.predict_batch([X, Xbad], [y, y], [Xs, Xs], [0.05, 0.05], [1e-2, 0.0])
 
 
+def test_reference_kernel_batch_mixes_small_and_large_orders(S):
+    """fit_batch(kernel='netdiffusion') with data sets either side of the one-workgroup limit (n <= 128): the small ones go through
+    the batched kernel, the large ones one at a time through the blocked engine, results in the caller's order; a non-SPD large
+    member reports its pivot like the small ones do."""
+    rng = np.random.default_rng(8)
+    sets = []
+    for n, N in ((40, 10), (300, 12), (128, 20), (129, 6)):
+        X = rng.standard_normal((n, N)); y = X @ rng.standard_normal(N) / np.sqrt(N) + 0.3 * rng.standard_normal(n)
+        sets.append((X, y, rng.standard_normal((2, N))))
+    Xbad = sets[1][0].copy(); Xbad[200:260] = Xbad[10:70]
+    sets.append((Xbad, sets[1][1], sets[1][2]))
+    ell = [0.05, 0.05, 0.2, 0.05, 0.05]; sn = [1e-1, 1e-1, 1.0, 1e-2, 0.0]
+    with S.GPR(kernel="netdiffusion") as gp:
+        r = gp.fit_batch([q[0] for q in sets], [q[1] for q in sets], [q[2] for q in sets], ell, sn)
+    assert list(r["info"][:4]) == [0, 0, 0, 0] and r["info"][4] > 0 and np.isinf(r["nlml"][4])
+    for i in range(4):
+        ref = O.fit_predict(sets[i][0], sets[i][1], sets[i][2], ell[i], sn[i], kind="netdiffusion", ref_idiom=False)
+        assert rel(r["mean"][i], ref["fmean"]) <= TOL_PRED and rel(r["var"][i], ref["fvar"]) <= TOL_PRED, i
+        assert rel(r["nlml"][i], ref["nlml"]) <= 1e-9 and rel(r["sigma_f"][i], ref["sigma_f"]) <= 1e-9, i
+
+
 def test_golden_scripts_through_the_batched_engine(S, golden):
     """All 14 reference scripts with every (region, year) fit in ONE launch (retro) / every region in one launch
     (operational): same acceptance as the fit-at-a-time test -- <= 1e-8, rounded outputs equal."""
