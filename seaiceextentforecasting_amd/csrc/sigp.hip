@@ -1053,7 +1053,7 @@ int sync_slot(sigp_handle* h, Slot& s) {
 // =====================================================================================================
 extern "C" {
 
-int sigp_version(void) { return 100; }
+int sigp_version(void) { return 200; }   // 2.0: + sigp_small_*, sigp_dist_local_*, sigp_corr_tau, sigp_area_sums, sigp_detrend, sigp_get_stat
 
 int sigp_create(sigp_handle** out, int device_id, int dtype) {
   if (!out) return SIGP_BAD_ARG;
