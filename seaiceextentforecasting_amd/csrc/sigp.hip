@@ -1134,7 +1134,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "pipeline_head")) { h->opt_pipeline_head = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 256) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
@@ -1696,6 +1696,8 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     hipStream_t sb = head ? s.s_pan : s.s_upd;
     if ((rc = upload_kparams(h, s, nb, sb))) return rc;
     if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m, sb))) return rc;
+    // pipeline_head = 2: only the covariance build (HBM / VALU work) runs under the previous group; the first panel waits too
+    if (head && h->opt_pipeline_head == 2 && g > 0) HIPCHK(h, hipStreamWaitEvent(s.s_pan, h->slots[(g - 1) % nslots].ev_group, 0));
     if ((rc = potrf_slot(h, s, nb, n_pad, head))) return rc;
     if ((rc = epilogue_slot(h, s, nb, n, n_pad, m))) return rc;
     if (head) HIPCHK(h, hipEventRecord(s.ev_group, s.s_upd));
