@@ -204,6 +204,25 @@ def main():
         gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
         prof_all = gp.profile_get(); gp.profile(False)
         prof_all_fits = kk
+    unshared = None
+    if not args.no_profile and rank == 0 and world == 1 and not args.no_extras:
+        # the same kernel NOT sharing the chip with the panel stream's strip solve: one extra, untimed pair of groups with the strip solve
+        # serialised behind the trailing update (option strips_after_update; slightly lower fits/s, which is why it is not the default)
+        gp.set_option("strips_after_update", 1)
+        kk = min(K, 2 * args.group)
+        gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
+        gp.profile(True, classes=["syrk128"]); gp.profile_reset()
+        torch.cuda.synchronize(); ta = time.perf_counter()
+        gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
+        torch.cuda.synchronize(); tu = time.perf_counter() - ta
+        pu = gp.profile_get()["syrk128"]; gp.profile(False)
+        gp.set_option("strips_after_update", 0)
+        if pu["ms"] > 0:
+            au = pu["flops"] / (pu["ms"] * 1e-3) / 1e12
+            unshared = {"achieved": au, "frac": au / PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "launches": pu["launches"], "avg_launch_ms": pu["ms"] / pu["launches"],
+                        "fits_per_s_with_this_schedule": kk / tu,
+                        "note": "syrk128_kernel when the panel stream's strip solve (MFMA work for the whole chip) waits for the trailing update instead of running beside it: "
+                                "the kernel's own rate; the default schedule overlaps them because the batch is ~1 % faster that way"}
     m64 = None
     if rank == 0 and world == 1 and not args.no_profile and not args.no_extras:
         # "m = 1 (also report m = 64)" -- the same steps with 64 test points riding along each fit (untimed extra)
@@ -256,6 +275,8 @@ def main():
                                "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "flops_note": "algorithmic: 2*128*128*K per off-diagonal tile, the lower half (128*129*K) per diagonal tile"}
+            if unshared is not None:
+                out["roofline"]["unshared"] = unshared
             # HBM-side traffic of the same kernel is NOT measured in this run: it comes from separate rocprofv3 --pmc passes of this
             # command (FETCH_SIZE / WRITE_SIZE cannot share a pass, and PMC collection serialises kernels), summarised under
             # profiles/ by tools/collect_profiles.sh + tools/summarize_pmc.py

@@ -137,6 +137,7 @@ struct sigp_handle {
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
+  int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
   int opt_update_late = 0;   // with update_wgs: only the outer updates of the last `update_late` panels run persistent (0 = all outer updates)
@@ -519,16 +520,23 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw, rlim))) return rc;
     return panel_rec(J0 + hw, Wp - hw, rlim);
   };
-  // factor block columns [J0, J0+Wp)
-  auto panel = [&](int J0, int Wp) -> int {
+  // factor block columns [J0, J0+Wp): panel_top = everything on the panel stream up to the strip solve (the whole panel when it
+  // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
+  auto use_strips = [&](int J0, int Wp) -> bool {
     const int below = R - (J0 + Wp);             // row blocks under the panel's top block (the ride block is one of them)
-    const bool strips = std::is_same<Real, double>::value && Wp > 1 && Wp <= MT_W && below > 0 &&
-                        (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
-    if (!strips) return panel_rec(J0, Wp, R);
+    return std::is_same<Real, double>::value && Wp > 1 && Wp <= MT_W && below > 0 &&
+           (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
+  };
+  auto panel_top = [&](int J0, int Wp) -> int {
+    if (!use_strips(J0, Wp)) return panel_rec(J0, Wp, R);
     // panel_mode 1: recursion on the top Wp x Wp block only, then every 128-row strip below it is solved by one
     // workgroup walking the panel's columns (panel_strip_kernel): the lower rows are read and written once
-    int rc = panel_rec(J0, Wp, J0 + Wp);
-    if (rc) return rc;
+    return panel_rec(J0, Wp, J0 + Wp);
+  };
+  auto panel_strips = [&](int J0, int Wp) -> int {
+    if (!use_strips(J0, Wp)) return SIGP_OK;
+    const int below = R - (J0 + Wp);
+    int rc;
     Real* mt = (Real*)s.mt;
     const long mtStride = MT_LD * MT_LD;
     {
@@ -553,6 +561,10 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       HIPCHK(h, hipGetLastError());
     }
     return SIGP_OK;
+  };
+  auto panel = [&](int J0, int Wp) -> int {
+    int rc = panel_top(J0, Wp);
+    return rc ? rc : panel_strips(J0, Wp);
   };
   auto outer = [&](hipStream_t st, int J, int Wc, int c0, int c1) -> int {
     // persistent form (update_wgs): only for outer trailing updates, and with update_late only for the last panels, where the
@@ -612,10 +624,20 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       if (rc) return rc;
       HIPCHK(h, hipEventRecord(s.ev_la, su));
       HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
-      rc = panel(J + Wc, Wn);                             // next panel overlaps the rest of the update
-      if (rc) return rc;
-      rc = outer(su, J, Wc, Wn, ncols);
-      if (rc) return rc;
+      if (h->opt_strips_after_update && use_strips(J + Wc, Wn)) {
+        // only the next panel's top block (a latency chain of small launches) overlaps the rest of the update; its strip solve --
+        // MFMA work for the whole chip -- starts when that update is done instead of sharing the chip with it
+        if ((rc = panel_top(J + Wc, Wn))) return rc;
+        if ((rc = outer(su, J, Wc, Wn, ncols))) return rc;
+        HIPCHK(h, hipEventRecord(s.ev_done, su));
+        HIPCHK(h, hipStreamWaitEvent(sp, s.ev_done, 0));
+        if ((rc = panel_strips(J + Wc, Wn))) return rc;
+      } else {
+        rc = panel(J + Wc, Wn);                           // next panel overlaps the rest of the update
+        if (rc) return rc;
+        rc = outer(su, J, Wc, Wn, ncols);
+        if (rc) return rc;
+      }
     } else {
       rc = outer(su, J, Wc, 0, ncols);
       if (rc) return rc;
@@ -1134,6 +1156,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
   if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
