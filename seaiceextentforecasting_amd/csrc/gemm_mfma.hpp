@@ -193,8 +193,11 @@ constexpr int gemm_lds_bytes() {
   return (2 * TM * Num<T>::LDP + (BT ? 2 * Num<T>::KT * (TN + 16) : 2 * TN * Num<T>::LDP)) * (int)sizeof(T);
 }
 
-template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
+// One TM x TN tile by 256 threads (tid = 0..255; `smem_raw` = gemm_lds_bytes<T, TM, TN, BT>() bytes of LDS).  The barriers inside
+// are workgroup-wide: a workgroup of two such 256-thread engines (diag_update_kernel) runs them in lockstep on equal K.
+// store = false: everything but the final write of the tile (an engine without a tile of its own keeps the barrier count).
+template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT, int PDX = 0>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgsT<T>& g, int bi, int bj, long bz, int tid, char* smem_raw, bool store) {
   static_assert(WM * WN == 4, "4 waves");
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
@@ -207,17 +210,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   constexpr int BTP = TN + 16;  // pitch of the [k][n] image (BT)
   static_assert(FM >= 1 && FN >= 1 && PA >= 1 && PB >= 1, "tile too small");
 
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* As = (T*)smem_raw;               // [2][TM][LDP]
   T* Bs = As + 2 * TM * LDPe;         // [2][TN][LDP]  or  [2][KT][BTP]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 15, lq = lane >> 4;
 
-  int bi, bj;
-  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
-  const long bz = blockIdx.y;
   const T* Ag = g.A + bz * g.sA + (long)bi * TM * g.lda;
   const T* Bg = BT ? g.B + bz * g.sB + (long)bj * TN : g.B + bz * g.sB + (long)bj * TN * g.ldb;
   T* Cg = g.C + bz * g.sC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
   // Register prefetch depth: small tiles (the latency-chain launches: panel solves, inner updates, block solves) keep PD K-slices
   // in flight in registers, so a slice costs max(MFMA time, global latency / PD) instead of a whole global-load latency; the LDS
   // image stays double-buffered (a slice goes to LDS one step before it is used).  The 128x128 tile has no registers to spare.
-  constexpr int PD = (TM * TN <= 64 * 64) ? 4 : 1;
+  constexpr int PD = PDX ? PDX : ((TM * TN <= 64 * 64) ? 4 : 1);
   v16_t va[PD][PA], vb[PD][PB];
 #define SIGP_GLOAD(k0, q)                                                                      \
   {                                                                                            \
@@ -315,12 +314,21 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
 #undef SIGP_GLOAD
 #undef SIGP_SSTORE
 
+  if (!store) return;
 #pragma unroll
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cg[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = acc[i][j][r];
+}
+
+template <typename T, int TM, int TN, int WM, int WN, int MODE, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmArgsT<T> g) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  int bi, bj;
+  if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
+  gemm_tile_body<T, TM, TN, WM, WN, MODE, BT>(g, bi, bj, (long)blockIdx.y, (int)threadIdx.x, smem_raw, true);
 }
 
 }  // namespace sigp

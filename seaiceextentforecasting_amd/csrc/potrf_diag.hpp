@@ -1,22 +1,27 @@
 // Diagonal-block kernel of the blocked Cholesky (north/June1st.py:265 np.linalg.cholesky -> dpotrf):
-// factor one 128x128 SPD block in LDS, write L11 back, then invert it in place and write inv(L11) to the
-// workspace so that the panel solve  L21 = A21 inv(L11)^T  is a plain MFMA GEMM.
+// factor one 128x128 SPD block in LDS, write L11 back, and form inv(L11) in the workspace so that the panel solve
+// L21 = A21 inv(L11)^T  is a plain MFMA GEMM.
 //
-// One 512-thread workgroup (the step is a latency chain, not throughput work).  The block lives in LDS
-// ([128][130] doubles: pitch 130 keeps the 8-byte MFMA fragment reads conflict free).  It is processed in
-// 16-column steps:
-//   B1  16x16 diagonal factorisation by ONE wave, rows in registers, pivots broadcast with v_readlane
-//       (wavefront shuffles, no LDS round trips, no barriers inside the step);
-//   B2  16-wide triangular solve of the rows below, one thread per row, L11 broadcast from LDS;
-//   B3  rank-16 update of the remaining lower tiles on v_mfma_f64_16x16x4_f64 -- with look-ahead: wave 0 takes the next
-//       diagonal tile first and runs B1 of the next step while the other waves finish the update, so the serial pivot chain
-//       of step jb+1 hides the bulk of B3 of step jb.
-// Register budget: the kernel must stay at <= 128 VGPRs (121 now).  Its 8 waves then take 2 x 128 of a SIMD's 512
-// registers and fit beside ONE resident wave of the trailing-update kernel (256 VGPRs); a 220-VGPR build (measured with a
-// DPP row_newbcast pivot loop, 7 % faster on an idle GPU) has to wait for BOTH update workgroups of a CU to finish:
-// 1.06 ms instead of 0.23 ms per launch in lockstep batches, -2 % fits/s.  Check `.vgpr_count` after touching it.
-// The inverse is formed with the in-place blocked lower-triangular recurrence (LAPACK dtrtri shape,
-// last block column first), again with MFMA for the block products.
+// One 512-thread workgroup: the step is a latency chain (128 dependent pivots), not throughput work, so the kernel is built
+// around keeping everything else off that chain.  The block lives in LDS as 36 lower 16x16 tiles (pitch 18: conflict-free
+// 8-byte MFMA fragment reads) and is processed in 16-column steps ("slots"); in every slot the eight waves have fixed roles:
+//   all waves first bring the NEXT block column up to date (rank-16 update, one tile per wave, one barrier); then
+//   pivot waves (wave 0, and wave 1 / 2 while there are more than three row tiles below): the 16 pivots of that column with the
+//       rows in registers -- lanes 0..15 hold the diagonal tile, lanes 16..63 three tiles of the rows below, so the row solve
+//       x L11^T = a is the same instruction stream as the pivot loop and costs nothing extra.  Pivots are LDL^T-style
+//       (reciprocal of the pivot + unscaled columns; the 16 inverse square roots are taken once, lane-parallel, after the loop):
+//       the dependent chain per pivot is v_rcp_f64 + 2 Newton steps instead of v_rsq_f64 + 2 Goldschmidt steps;
+//   MFMA waves (the others): the rank-16 update of the remaining trailing tiles (v_mfma_f64_16x16x4_f64), then row s of the
+//       INVERSE by bordering:  X(s,j) = -X(s,s) sum_{k=j}^{s-1} L(s,k) X(k,j)  -- the rows above are complete, the sums need
+//       no data of this slot, and only the last product waits (LDS flag) for
+//   wave 7: writes row s of L back to global memory, inverts the 16x16 diagonal tile (forward substitution, one lane per
+//       column), raises the flag, and streams the finished row s-1 of the inverse to the workspace.
+// The inverse is therefore complete one short tail (last tile inverse + one product) after the last pivot, instead of a
+// separate phase of 3 levels x 4 barriers; results that overwrite tiles other waves still read are held in registers over the
+// slot's closing barrier and written before the next slot's opening barrier.
+// Register budget: the kernel must stay at <= 128 VGPRs.  Its 8 waves then take 2 x 128 of a SIMD's 512 registers and fit
+// beside ONE resident wave of the trailing-update kernel (256 VGPRs); a 220-VGPR build has to wait for BOTH update workgroups
+// of a CU to finish: 1.06 ms instead of 0.23 ms per launch in lockstep batches.  Check `.vgpr_count` (make resources).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -25,11 +30,13 @@
 namespace sigp {
 
 constexpr int DB = 128;   // diagonal block size
-constexpr int BP = 18;    // pitch (doubles) inside a 16x16 LDS block: conflict-free 8-byte MFMA fragment reads
+constexpr int BP = 18;    // pitch (elements) inside a 16x16 LDS tile: conflict-free 8-byte MFMA fragment reads
 constexpr int BSZ = 16 * BP;
-// LDS holds only the 36 lower 16x16 blocks (block-packed) + the reciprocal diagonal: 84 KB, so the kernel can
-// share a CU with one resident trailing-update workgroup (64 KB) instead of waiting for a whole CU to drain.
-constexpr int DIAG_LDS_BYTES = (36 * BSZ + DB) * (int)sizeof(double);   // fp64 size; fp32 needs half
+constexpr int DIAG_XT = 1;   // wave 0's copy of the factored diagonal tile (moved into the block one barrier later)
+// LDS: the 36 lower tiles + that copy + the reciprocal diagonal + 8 flag words: 86 KB in fp64, so the kernel
+// shares a CU with one resident trailing-update workgroup (64 KB) instead of waiting for a whole CU to drain.
+template <typename T> constexpr int diag_lds_bytes() { return ((36 + DIAG_XT) * BSZ + DB) * (int)sizeof(T) + 64; }
+constexpr int DIAG_LDS_BYTES = diag_lds_bytes<double>();
 constexpr int DIAG_THREADS = 512;
 
 __device__ inline double readlane_t(double x, int l) {
@@ -41,6 +48,8 @@ __device__ inline double readlane_t(double x, int l) {
 __device__ inline float readlane_t(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ inline double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
 __device__ inline float rsq_seed(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ inline double rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }
+__device__ inline float rcp_seed(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * BSZ; }   // bj <= bi
 
 // A: the 128x128 block inside the big matrix (row stride lda); Linv: [128][128] row-major workspace whose
@@ -48,97 +57,47 @@ __device__ inline int dblk(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * B
 // info: device word, first failing 1-based global pivot index (0 = none yet); pivot_base: global index of row 0.
 // blockIdx.x = batch member: A += b*strideA, Linv += b*strideL, info += b.
 template <typename T>
-__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv,
-                                                                  int* __restrict__ info, int pivot_base, int skip_in, long strideA,
-                                                                  long strideL) {
-  const int skip = skip_in & (DBG_MASK | 32);   // bits 1..16: phase ablations of tools/diag_bench.py (debug library only)
+__device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* __restrict__ Linv, int* __restrict__ info, int pivot_base,
+                                                int flags, char* smem_raw) {
+  const int skip = flags & DBG_MASK;   // timing ablations of tools/diag_bench.py (debug library only): 1 no pivot loop, 2 no MFMA-wave
+                                       // work, 4 no wave-7 work, 8 no pivot-wave update, 16 no global loads/stores of the tiles
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
   typedef typename N_::v2_t v2_t;
-  // latency chain on the critical path of every panel, co-resident with MFMA-saturating update waves: ask the
-  // instruction arbiter for the highest wave priority (bit 32 of `skip` disables it, for A/B timing)
-  if (!(skip & 32)) __builtin_amdgcn_s_setprio(3);
-  A += blockIdx.x * strideA;
-  Linv += blockIdx.x * strideL;
-  info += blockIdx.x;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* S = (T*)smem_raw;               // 36 blocks of [16][18]
-  T* dinv = S + 36 * BSZ;            // [128] reciprocals of the diagonal of L
+  T* S = (T*)smem_raw;               // 36 tiles of [16][18]
+  T* XT = S + 36 * BSZ;              // wave 0: the factored diagonal tile until commit_diag
+  T* dinv = XT + DIAG_XT * BSZ;      // [128] reciprocals of the diagonal of L
+  volatile int* flag = (volatile int*)(dinv + DB);   // flag[b] = 1: tile (b, b) holds its inverse
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lq = lane >> 4;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int lane = tid & 63;
+  int lr = lane & 15, lq = lane >> 4;
+  // latency chain on the critical path of every panel, co-resident with MFMA-saturating update waves: ask the instruction
+  // arbiter for a high wave priority, the pivot loop above the kernel's own MFMA waves (bit 32 of `flags` disables it: A/B timing)
+  if (!(flags & 32)) {
+    if (wave < 2) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(2);
+  }
 
   // ---- load the lower triangle of the block ----
 #pragma unroll
   for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
     const int idx = tid + it * DIAG_THREADS;
     const int row = idx >> 6, cp = (idx & 63) * 2;
-    if (cp <= row) *(v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = *(const v2_t*)(A + (long)row * lda + cp);
+    if (cp <= row && !(skip & 16)) {
+      const v2_t v = *(const v2_t*)(A + (long)row * lda + cp);
+      *(v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = v;
+    }
   }
+  if (tid < 8) flag[tid] = 0;
   __syncthreads();
 
-  // ---- factorisation, 8 steps of 16 columns ----
-  // B1: 16x16 Cholesky of the diagonal tile jb by ONE wave; lane i (mod 16) holds row i; pivots via v_readlane; 1/sqrt by
-  // v_rsq_f64 + Goldschmidt
-  auto factor16 = [&](int jb) {
-    T* Sjj = S + dblk(jb, jb);
-    T r[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) r[c] = Sjj[lr * BP + c];
-    // Branch-free: the 16 pivots are ONE basic block, so the scheduler can run the tail of pivot j's column updates under the
-    // rsq / Goldschmidt latency of pivot j+1 (a per-pivot `if` for the failure case cut the block and serialised them).
-    int bad = 0;          // first non-positive / NaN pivot of this tile (1-based), uniform
-    T myinv = (T)0;       // lane j keeps 1/L_jj
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      T dj = readlane_t(r[j], j);
-      const bool neg = !(dj > (T)0);
-      bad = (neg && bad == 0) ? j + 1 : bad;
-      dj = neg ? (T)1 : dj;
-      const T y0 = rsq_seed(dj);
-      T g = dj * y0, hh = (T)0.5 * y0;
-      T e = fma(-hh, g, (T)0.5);
-      g = fma(g, e, g); hh = fma(hh, e, hh);
-      e = fma(-hh, g, (T)0.5);
-      g = fma(g, e, g); hh = fma(hh, e, hh);
-      const T e2 = fma(-g, g, dj);
-      const T s = fma(e2, hh, g);      // sqrt(dj)
-      const T inv = hh + hh;           // 1/sqrt(dj)
-      const T lij = (lr == j) ? s : r[j] * inv;
-      r[j] = lij;
-      myinv = (lr == j) ? inv : myinv;
-#pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        const T lcj = readlane_t(lij, c);
-        r[c] = fma(-lij, lcj, r[c]);
-      }
-    }
-    if (lane < 16) {
-      dinv[jb * 16 + lr] = myinv;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) Sjj[lr * BP + c] = (c <= lr) ? r[c] : (T)0;
-    }
-    // LAPACK info = index of the first failing pivot
-    if (bad != 0 && lane == 0 && *info == 0) *info = pivot_base + jb * 16 + bad;
-  };
-  // one 16x16 tile of the rank-16 update: C(ti, tj) -= L(ti, jb) L(tj, jb)^T  (two of them interleaved so that one's MFMA
-  // dependency chain hides behind the other's)
-  auto update_pair = [&](int jb, int t, bool two, int t2) {
-    int ti0 = 0, rem = t;
-    while (rem > ti0) { rem -= ti0 + 1; ++ti0; }
-    const int tj0 = rem;
-    int ti1 = 0; rem = two ? t2 : t;
-    while (rem > ti1) { rem -= ti1 + 1; ++ti1; }
-    const int tj1 = rem;
-    T* C0 = S + dblk(jb + 1 + ti0, jb + 1 + tj0);
-    T* C1 = S + dblk(jb + 1 + ti1, jb + 1 + tj1);
-    const T* A0 = S + dblk(jb + 1 + ti0, jb), *B0 = S + dblk(jb + 1 + tj0, jb);
-    const T* A1 = S + dblk(jb + 1 + ti1, jb), *B1 = S + dblk(jb + 1 + tj1, jb);
+  // one tile of a rank-16 step:  Cd = Cs - A_ B_^T  (two tiles interleaved: one's MFMA chain hides behind the other's)
+  auto upd2 = [&](const T* Cs0, T* Cd0, const T* A0, const T* B0, bool two, const T* Cs1, T* Cd1, const T* A1, const T* B1) {
     acc_t acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      acc0[r] = C0[N_::drow(lq, r) * BP + lr];
-      acc1[r] = C1[N_::drow(lq, r) * BP + lr];
+      acc0[r] = Cs0[N_::drow(lq, r) * BP + lr];
+      acc1[r] = Cs1[N_::drow(lq, r) * BP + lr];
     }
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -150,142 +109,232 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
       acc1 = N_::mfma(a1, b1, acc1);
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) C0[N_::drow(lq, r) * BP + lr] = acc0[r];
+    for (int r = 0; r < 4; ++r) Cd0[N_::drow(lq, r) * BP + lr] = acc0[r];
     if (two) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) C1[N_::drow(lq, r) * BP + lr] = acc1[r];
+      for (int r = 0; r < 4; ++r) Cd1[N_::drow(lq, r) * BP + lr] = acc1[r];
     }
   };
 
-  if (wave == 0 && !(skip & 1)) factor16(0);
-  __syncthreads();
-  for (int jb = 0; jb < 8; ++jb) {
-    T* Sjj = S + dblk(jb, jb);
-    // B2: rows below: x L11^T = a   (one thread per row)
-    const int nrows = DB - (jb * 16 + 16);
-    if (tid < nrows && !(skip & 2)) {
-      const int row = jb * 16 + 16 + tid;
-      T* Sr = S + dblk(row >> 4, jb) + (row & 15) * BP;
-      T x[16];
+  // ---- pivot wave: block column jb of the rows this wave holds (lanes 0..15 the diagonal tile, from `dsrc`; lanes 16q..16q+15
+  // row tile jb + 3w + q).  The row tiles below are written back in place, the diagonal
+  // tile is left in wave 0's copy and moved into the block before the next slot's opening barrier (commit_diag).
+  auto pivot_column = [&](int jb, int w) {
+    T r[16];
+    const int bt = jb + 3 * w + lq;
+    const bool below = lq > 0 && bt <= 7;
+    T* tile = S + dblk(below ? bt : jb, jb);        // lanes without a row tile walk the diagonal tile too (results unused)
 #pragma unroll
-      for (int c = 0; c < 16; ++c) x[c] = Sr[c];
+    for (int c = 0; c < 16; ++c) r[c] = tile[lr * BP + c];
+    // Branch-free: the 16 pivots are ONE basic block, so the scheduler can run the tail of pivot j's column updates under the
+    // reciprocal latency of pivot j+1.
+    int bad = 0;          // first non-positive / NaN pivot of this tile (1-based), uniform
+    T myd = (T)1;         // lane j (diagonal rows) keeps d_j
+    if (!(skip & 1))
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        x[j] *= dinv[jb * 16 + j];
+    for (int j = 0; j < 16; ++j) {
+      T dj = readlane_t(r[j], j);
+      const bool neg = !(dj > (T)0);
+      bad = (neg && bad == 0) ? j + 1 : bad;
+      dj = neg ? (T)1 : dj;
+      myd = (lq == 0 && lr == j) ? dj : myd;
+      T x = rcp_seed(dj);
+      T e = fma(-dj, x, (T)1);
+      x = fma(x, e, x);
+      e = fma(-dj, x, (T)1);
+      x = fma(x, e, x);                // 1 / d_j
+      const T t = r[j] * x;            // u_ij / d_j
 #pragma unroll
-        for (int p = j + 1; p < 16; ++p) x[p] = fma(-x[j], Sjj[p * BP + j], x[p]);
+      for (int c = j + 1; c < 16; ++c) {
+        const T ucj = readlane_t(r[j], c);
+        r[c] = fma(-t, ucj, r[c]);
       }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) Sr[c] = x[c];
     }
-    __syncthreads();
-    // B3 with look-ahead: wave 0 updates the NEXT diagonal tile (tile 0 of the trailing grid) and factors it straight away
-    // (B1 of step jb + 1, the serial pivot chain) while waves 1..7 apply the rank-16 update to all the other lower tiles of
-    // the trailing (7-jb)x(7-jb) block grid, two tiles per iteration.
-    const int nb = 7 - jb;
-    const int nt = nb * (nb + 1) / 2;
+    // 1 / sqrt(d) for the 16 pivots at once (lane j: d_j): v_rsq + two Goldschmidt steps
+    const T y0 = rsq_seed(myd);
+    T g = myd * y0, hh = (T)0.5 * y0;
+    T e = fma(-hh, g, (T)0.5);
+    g = fma(g, e, g); hh = fma(hh, e, hh);
+    e = fma(-hh, g, (T)0.5);
+    g = fma(g, e, g); hh = fma(hh, e, hh);
+    const T e2 = fma(-g, g, myd);
+    const T sq = fma(e2, hh, g);       // sqrt(d)
+    const T rs = hh + hh;              // 1 / sqrt(d)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) r[j] *= readlane_t(rs, j);
+    if (below) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) tile[lr * BP + c] = r[c];
+    } else if (w == 0 && lq == 0) {    // the factored diagonal tile stays in wave 0's copy until commit_diag
+      dinv[jb * 16 + lr] = rs;         // (first read by the tile inverse of the next slot)
+#pragma unroll
+      for (int c = 0; c < 16; ++c) XT[lr * BP + c] = (c < lr) ? r[c] : (c == lr ? sq : (T)0);
+    }
+    // LAPACK info = index of the first failing pivot
+    if (w == 0 && bad != 0 && lane == 0 && *info == 0) *info = pivot_base + jb * 16 + bad;
+  };
+  auto commit_diag = [&](int jb) {     // wave 0: its copy of the factored diagonal tile -> the block
     if (wave == 0) {
-      if (nt > 0 && !(skip & 4)) update_pair(jb, 0, false, 0);
-      if (jb < 7 && !(skip & 1)) factor16(jb + 1);
-    } else if (!(skip & 4)) {
-      for (int t = wave; t < nt; t += 14) update_pair(jb, t, (t + 7) < nt, t + 7);
+      T* Sjj = S + dblk(jb, jb);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = (lane >> 3) + 8 * p, cp = (lane & 7) * 2;
+        *(v2_t*)(Sjj + row * BP + cp) = *(const v2_t*)(XT + row * BP + cp);
+      }
     }
-    __syncthreads();
-  }
+  };
+  // one 16x16 tile LDS -> global, lower part only when `diag` (rows of 16 elements = 8 pairs; 64 lanes x 2 passes)
+  auto store_tile = [&](const T* tile, T* G, long ldg, bool diag) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int row = (lane >> 3) + 8 * p, cp = (lane & 7) * 2;
+      if (!diag || cp <= row) *(v2_t*)(G + (long)row * ldg + cp) = *(const v2_t*)(tile + row * BP + cp);
+    }
+  };
 
-  // ---- write L11 back (lower triangle only; the strictly-upper part of the block is never read) ----
-#pragma unroll
-  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
-    const int idx = tid + it * DIAG_THREADS;
-    const int row = idx >> 6, cp = (idx & 63) * 2;
-    if (cp <= row) {
-      v2_t v = *(const v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
-      if (cp + 1 > row) v.y = (T)0;
-      *(v2_t*)(A + (long)row * lda + cp) = v;
-    }
-  }
-
-  if (skip & 8) return;
-  __syncthreads();   // the diagonal blocks are about to be overwritten by their inverses
-  // ---- inverse: 16x16 diagonal-block inverses in place (columns of inv(L_bb) by forward substitution) ----
-  if (wave < 2) {
-    const int b = wave * 4 + lq, c = lr;
-    T* Sbb = S + dblk(b, b);
-    T x[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) x[i] = (i == c) ? (T)1 : (T)0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      x[i] *= dinv[b * 16 + i];
-#pragma unroll
-      for (int p = i + 1; p < 16; ++p) x[p] = fma(-Sbb[p * BP + i], x[i], x[p]);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 16; ++i) Sbb[i * BP + c] = x[i];
-  }
+  if (wave < 3) pivot_column(0, wave);
   __syncthreads();
 
-  // ---- blocked in-place inverse by recursive doubling:  [L11 0; L21 L22]^-1 = [X11 0; -X22 (L21 X11)  X22] ----
-  // Level s (in 16x16 tiles, s = 1, 2, 4) joins the 8/(2s) pairs of finished s-tile inverse blocks: first P = L21 X11 (it
-  // overwrites L21, whose copy in global memory was written back above), then X21 = -X22 P; the 4s tiles of a level are
-  // dealt over the 8 waves (two per wave at s = 4).  3 levels x 4 barriers and dependency chains of at most 16 MFMAs,
-  // against 7 column steps x 2 barriers with chains of up to 28 in the column-by-column recurrence this replaces (9.7 us).
-  for (int sblk = 1; sblk < 8 && !(skip & 16); sblk *= 2) {
-    const int ntile = 4 * sblk, s2 = sblk * sblk;
+  acc_t pend;               // an MFMA wave's finished inverse tile X(s, pend_j)^T, written before the next opening barrier
+  int pend_j = -1;
+  for (int s = 0; s < 8; ++s) {
+    // keep the lane-index arithmetic of the three roles inside the loop: hoisted out of it (per-element LDS offsets of every
+    // branch kept live over the whole kernel) it costs 60 VGPRs
+    asm volatile("" : "+v"(lane));
+    lr = lane & 15; lq = lane >> 4;
+    // ---- writes held back over the closing barrier: the diagonal tile of column s, row s-1 of the inverse ----
+    commit_diag(s);
+    if (pend_j >= 0) {
+      T* D = S + dblk(s - 1, pend_j);
 #pragma unroll
-    for (int phase = 0; phase < 2; ++phase) {
-      acc_t res[2];
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) res[q][r] = (T)0;
-        const int t = wave + 8 * q;
-        if (t < ntile) {
-          const int pair = t / s2, w = t - pair * s2, i = w / sblk, j = w - i * sblk;
-          const int b0 = pair * 2 * sblk;
-          // phase 0:  P(i, j)   = sum_{k = j}^{s-1} L21(i, k) X11(k, j)      (X11 lower triangular)
-          // phase 1:  X21(i, j) = -sum_{k = 0}^{i}  X22(i, k) P(k, j)        (X22 lower triangular)
-          const int k0 = phase == 0 ? j : 0, k1 = phase == 0 ? sblk - 1 : i;
-          for (int k = k0; k <= k1; ++k) {
-            const T* A_ = phase == 0 ? S + dblk(b0 + sblk + i, b0 + k) : S + dblk(b0 + sblk + i, b0 + sblk + k);
-            const T* B_ = phase == 0 ? S + dblk(b0 + k, b0 + j) : S + dblk(b0 + sblk + k, b0 + j);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-              T a_ = A_[lr * BP + kk * 4 + lq];           // (row lr, k)
-              const T b_ = B_[(kk * 4 + lq) * BP + lr];   // (k, col lr)
-              if (phase == 1) a_ = -a_;
-              res[q] = N_::mfma(a_, b_, res[q]);
-            }
-          }
-        }
-      }
-      __syncthreads();   // every read of the blocks about to be overwritten (L21, then P) is done
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int t = wave + 8 * q;
-        if (t < ntile) {
-          const int pair = t / s2, w = t - pair * s2, i = w / sblk, j = w - i * sblk;
-          T* D = S + dblk(pair * 2 * sblk + sblk + i, pair * 2 * sblk + j);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) D[N_::drow(lq, r) * BP + lr] = res[q][r];
-        }
-      }
-      __syncthreads();
+      for (int q = 0; q < 4; ++q) D[lr * BP + N_::drow(lq, q)] = pend[q];
+      pend_j = -1;
     }
+    __syncthreads();
+    const int jn = s + 1;                               // the block column the pivot waves work on in this slot
+    // rank-16 update (column s) of block column jn, one tile per wave (the pivot loop needs all of them: with every SIMD's matrix
+    // pipe on it the step is one 4-MFMA chain instead of up to four on the pivot wave's own)
+    if (s < 7 && wave <= 7 - jn && !(skip & 8)) {
+      T* Cn = S + dblk(jn + wave, jn);
+      upd2(Cn, Cn, S + dblk(jn + wave, s), S + dblk(jn, s), false, Cn, Cn, S + dblk(jn + wave, s), S + dblk(jn, s));
+    }
+    if (s < 7) __syncthreads();
+    const bool pivot_wave = s < 7 && (wave == 0 || (wave == 1 && s <= 2));
+    if (pivot_wave) {
+      const int w = wave;
+      pivot_column(jn, w);
+    } else if (wave == 7) {
+      // row s of L -> global; inverse of the diagonal tile in place; row s-1 of the inverse -> workspace
+      if (!(skip & 16)) store_tile(S + dblk(s, s), A + (long)(s * 16) * lda + s * 16, lda, true);
+      if (lane < 16 && !(skip & 4)) {
+        const int c = lr;
+        T* Sbb = S + dblk(s, s);
+        T x[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = (i == c) ? (T)1 : (T)0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          x[i] *= dinv[s * 16 + i];
+#pragma unroll
+          for (int p = i + 1; p < 16; ++p) x[p] = fma(-Sbb[p * BP + i], x[i], x[p]);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Sbb[i * BP + c] = x[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) flag[s] = 1;
+      if (!(skip & 16)) {
+      for (int k = 0; k < s; ++k) store_tile(S + dblk(s, k), A + (long)(s * 16) * lda + k * 16, lda, false);
+      if (s > 0)
+        for (int k = 0; k < s; ++k) store_tile(S + dblk(s - 1, k), Linv + (long)((s - 1) * 16) * DB + k * 16, DB, k == s - 1);
+      if (s == 7) store_tile(S + dblk(7, 7), Linv + (long)(7 * 16) * DB + 7 * 16, DB, true);
+      }
+    } else if (!(skip & 2)) {
+      // MFMA waves: index m among the nm of this slot
+      const int nm = (s == 7) ? 7 : (s >= 3 ? 6 : 5);
+      const int m = (s == 7) ? wave : (s >= 3 ? wave - 1 : wave - 2);
+      // rank-16 update (column s) of the trailing tiles (i, k), s+2 <= k <= i <= 7, two per iteration
+      const int nb = 6 - s;
+      const int nt = nb > 0 ? nb * (nb + 1) / 2 : 0;
+      auto tile_of = [&](int t, int& ti, int& tj) { ti = 0; int rem = t; while (rem > ti) { rem -= ti + 1; ++ti; } tj = rem; };
+      for (int t = (m + nm - (s % nm)) % nm; t < nt; t += 2 * nm) {
+        const bool two = t + nm < nt;
+        int i0, k0, i1, k1;
+        tile_of(t, i0, k0);
+        tile_of(two ? t + nm : t, i1, k1);
+        i0 += s + 2; k0 += s + 2; i1 += s + 2; k1 += s + 2;
+        T* C0 = S + dblk(i0, k0);
+        T* C1 = S + dblk(i1, k1);
+        upd2(C0, C0, S + dblk(i0, s), S + dblk(k0, s), two, C1, C1, S + dblk(i1, s), S + dblk(k1, s));
+      }
+      // row s of the inverse: tile j = m (the longest sums go to the first waves)
+      if (m < s) {
+        const int j = m;
+        acc_t q;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) q[i] = (T)0;
+        for (int k = j; k < s; ++k) {
+          const T* A_ = S + dblk(s, k);
+          const T* B_ = S + dblk(k, j);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) q = N_::mfma(A_[lr * BP + kk * 4 + lq], B_[(kk * 4 + lq) * BP + lr], q);
+        }
+        for (int spin = 0; flag[s] == 0 && spin < (1 << 20); ++spin) __builtin_amdgcn_s_sleep(1);   // (wave 7 raises it unconditionally)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // X(s,j)^T = -Q^T X(s,s)^T: the accumulator layout of Q is the A-operand layout of Q^T (k = the accumulator's row)
+        const T* Xss = S + dblk(s, s);
+        acc_t res;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res[i] = (T)0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) res = N_::mfma(q[i], -Xss[lr * BP + N_::drow(lq, i)], res);
+        if (s < 7) {
+          pend = res; pend_j = j;
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) Linv[(long)(7 * 16 + lr) * DB + j * 16 + N_::drow(lq, i)] = res[i];
+        }
+      }
+    }
+    if (s < 7) __syncthreads();
   }
+}
 
-  // ---- write inv(L11) (lower triangle) ----
-#pragma unroll
-  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
-    const int idx = tid + it * DIAG_THREADS;
-    const int row = idx >> 6, cp = (idx & 63) * 2;
-    if (cp <= row) {
-      v2_t v = *(const v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15));
-      if (cp + 1 > row) v.y = (T)0;
-      *(v2_t*)(Linv + row * DB + cp) = v;
-    }
+template <typename T>
+__global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv,
+                                                                  int* __restrict__ info, int pivot_base, int flags, long strideA,
+                                                                  long strideL) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  potrf_diag_body<T>(A + blockIdx.x * strideA, lda, Linv + blockIdx.x * strideL, info + blockIdx.x, pivot_base, flags, smem_raw);
+}
+
+// The diagonal block of column c+1 AND, beside it, the rank-128 update of the panel's columns c+2.. with column c: one launch.
+// On the panel stream the chain is  diagonal block -> column solve -> update of the next column -> diagonal block ...; the update
+// of the panel's OTHER columns is most of a panel's flops but nothing on the chain needs it before the column solve that follows
+// this launch.  As a launch of its own on the same stream it sits in the chain (30 us per column); on a second stream every
+// hand-off is an inter-queue barrier packet (7-13 us each, measured).  As extra workgroups of the diagonal-block launch it costs
+// nothing: workgroups 0..nb-1 factor (one per lockstep member), every other workgroup is two 256-thread 64x64-tile engines of
+// the generic update (same arithmetic, same k order: bit-identical to separate launches) running in lockstep on equal K.
+static_assert(2 * gemm_lds_bytes<double, 64, 64, false>() <= DIAG_LDS_BYTES, "fp64: the update engines live in the diagonal block's LDS allocation");
+template <typename T>
+__global__ __launch_bounds__(DIAG_THREADS, 4) void diag_update_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv, int* __restrict__ info,
+                                                                   int pivot_base, int flags, long strideA, long strideL, int nb,
+                                                                   GemmArgsT<T> g, int ntile, int wgs) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if ((int)blockIdx.x < nb) {
+    potrf_diag_body<T>(A + blockIdx.x * strideA, lda, Linv + blockIdx.x * strideL, info + blockIdx.x, pivot_base, flags, smem_raw);
+    return;
   }
+  const int u = (int)blockIdx.x - nb;
+  const int bz = u / wgs, w = u - bz * wgs;
+  const int e = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  int t = 2 * w + e;
+  const bool own = t < ntile;
+  if (!own) t = ntile - 1;          // odd tile count: the last workgroup's second engine shadows the first (no store)
+  int bi = 0, bj = 0;
+  gemm_tile_coords(g, t, bi, bj);
+  gemm_tile_body<T, 64, 64, 2, 2, GEMM_SUB, false, 2>(g, bi, bj, (long)bz, (int)threadIdx.x & 255, smem_raw + e * gemm_lds_bytes<T, 64, 64, false>(), own);
 }
 
 }  // namespace sigp

@@ -137,6 +137,10 @@ struct sigp_handle {
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
+  int opt_first_on_panel = 1;        // right-looking + look-ahead: the update of the next panel's columns runs on the panel stream: 0 never,
+                                     // 1 when that panel is a latency chain (not strip-solved: single fits, small groups), 2 always
+  int opt_panel_chain = 1;           // panels that are not strip-solved (single fits, small groups): right-looking, column by column; only the next
+                                     // column's update is a launch of its own, the other columns' update rides in the diagonal-block launch
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
@@ -393,7 +397,9 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
     return launch_gemm_cfg<T, 128, 128, 2, 2, GEMM_SUB, false>(h, st, g);
   }
   ProfScope ps(h, st, SIGP_KC_UPDATE_SMALL, flops, bytes);
-  if (nt * 4 <= h->opt_tiny_tiles) {            // so few 64-tiles that most SIMDs would idle: 32x32 tiles, a quarter of the MFMA chain per wave
+  if (nt * 4 <= h->opt_tiny_tiles && g.K <= 2 * NB) {   // so few 64-tiles that most SIMDs would idle: 32x32 tiles, a quarter of the MFMA chain per
+                                                        // wave.  Short K only: at K = 1024 the 32x32 tiles' operand traffic (4 flop/B) is what the
+                                                        // launch waits for (53-61 us for the 41-tile update before the last panel of n = 4096)
     g.r0 *= 4; g.r1 *= 4; g.c0 *= 4; g.c1 *= 4;
     return launch_gemm_cfg<T, 32, 32, 2, 2, GEMM_SUB, false>(h, st, g);
   }
@@ -443,7 +449,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
   const int W = std::max(1, h->opt_outer);
-  constexpr int diag_lds = (36 * BSZ + DB) * (int)sizeof(Real);
+  constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
     if (rcm) return rcm;
@@ -464,7 +470,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   }
 
   // lower-trapezoid update  C[cols ccol0.., rows >= col .. R) -= P P^T,  P = L[:, kcol0 .. kcol0+kw)
-  auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1, int rlim) -> int {
+  auto update_args = [&](int kcol0, int kw, int ccol0, int c0, int c1, int rlim) -> GemmArgsT<Real> {
     const long o = (long)ccol0 * NB;
     GemmArgsT<Real> g{};
     g.A = M + o * ld + (long)kcol0 * NB; g.lda = ld;
@@ -472,37 +478,59 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     g.C = M + o * ld + o; g.ldc = ld;
     g.batch = nb; g.sA = g.sB = g.sC = matStride;
     g.K = kw * NB; g.r0 = 0; g.r1 = rlim - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
+    return g;
+  };
+  auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1, int rlim) -> int {
     (void)kclass;
-    return gemm_sub_auto(h, st, g);
+    return gemm_sub_auto(h, st, update_args(kcol0, kw, ccol0, c0, c1, rlim));
+  };
+  // diagonal block of column c (factor + inverse); `gu` (64-tile units) = an update whose tiles ride in the same launch
+  auto diag_block = [&](int c, const GemmArgsT<Real>* gu) -> int {
+    const int ntile = gu ? gemm_grid_size(gu->r0, gu->r1, gu->c0, gu->c1, gu->lower, 0) : 0;
+    const double uflops = gu ? nb * (double)ntile * 2.0 * 64 * 64 * gu->K : 0.0;
+    ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3 + uflops, nb * 3.0 * NB * NB * 8 + nb * (double)ntile * 2.0 * 64 * 64 * sizeof(Real));
+    Real* Ac = M + (long)c * NB * ld + (long)c * NB;
+    const int flags = h->opt_diag_prio ? 0 : 32;
+    if (ntile > 0) {
+      static AttrOnce du_attr;
+      constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());   // (fp32: the two update engines need more than the block)
+      HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
+      const int wgs = (ntile + 1) / 2;
+      hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(nb + nb * wgs), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info,
+                         c * NB, flags, matStride, dinvStride, nb, *gu, ntile, wgs);
+    } else {
+      hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB,
+                         flags, matStride, dinvStride);
+    }
+    HIPCHK(h, hipGetLastError());
+    return SIGP_OK;
+  };
+  // rows below the diagonal block of column c:  L[c+1.., c] = A[c+1.., c] inv(L_cc)^T
+  auto solve_column = [&](int c, int rlim) -> int {
+    const long o = (long)(c + 1) * NB;
+    const int rows_below = rlim - (c + 1);   // 128-row blocks below the diagonal block (ride block included when rlim = R)
+    if (rows_below <= 0) return SIGP_OK;
+    GemmArgsT<Real> g{};
+    g.A = M + o * ld + (long)c * NB; g.lda = ld;
+    g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
+    g.C = M + o * ld + (long)c * NB; g.ldc = ld;
+    g.batch = nb; g.sA = g.sC = matStride; g.sB = dinvStride;
+    g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
+    if (rows_below * nb >= h->opt_trsm128) {   // enough 128-row tiles to fill the chip: the LDS-DMA kernel
+      g.r1 = rows_below;
+      return launch_syrk128_t<Real, true>(h, sp, g);
+    }
+    g.r1 = rows_below * 4;                     // few rows: 32-row tiles for parallelism
+    return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   };
   // factor block columns [J0, J0+Wp) (already up to date) by binary recursion: the left half, a rank-(half) update
   // of the right half's columns, then the right half.
   // rlim = one past the last row block the recursion touches: R for the whole panel, J0+Wp for its top block only
   std::function<int(int, int, int)> panel_rec = [&](int J0, int Wp, int rlim) -> int {
     if (Wp == 1) {
-      const int c = J0;
-      {
-        ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3, nb * 3.0 * NB * NB * 8);
-        hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, M + (long)c * NB * ld + (long)c * NB, ld,
-                           dinvp + (long)c * NB * NB, s.info, c * NB, h->opt_diag_prio ? 0 : 32, matStride, dinvStride);
-        HIPCHK(h, hipGetLastError());
-      }
-      const long o = (long)(c + 1) * NB;
-      const int rows_below = rlim - (c + 1);   // 128-row blocks below the diagonal block (ride block included when rlim = R)
-      if (rows_below <= 0) return SIGP_OK;
-      GemmArgsT<Real> g{};
-      g.A = M + o * ld + (long)c * NB; g.lda = ld;
-      g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
-      g.C = M + o * ld + (long)c * NB; g.ldc = ld;
-      g.batch = nb; g.sA = g.sC = matStride; g.sB = dinvStride;
-      g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
-      ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
-      if (rows_below * nb >= h->opt_trsm128) {   // enough 128-row tiles to fill the chip: the LDS-DMA kernel
-        g.r1 = rows_below;
-        return launch_syrk128_t<Real, true>(h, sp, g);
-      }
-      g.r1 = rows_below * 4;                     // few rows: 32-row tiles for parallelism
-      return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+      int rc1 = diag_block(J0, nullptr);
+      return rc1 ? rc1 : solve_column(J0, rlim);
     }
     if (h->opt_panel_ll && Wp <= h->opt_panel_ll) {
       // left-looking inside a (sub)panel: column block c is updated once with all earlier columns of the panel
@@ -520,6 +548,33 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw, rlim))) return rc;
     return panel_rec(J0 + hw, Wp - hw, rlim);
   };
+  // The same panel, right-looking and column by column (same k order per tile: bit-identical), arranged around the latency chain
+  // diagonal block -> column solve -> update of the NEXT column -> next diagonal block: the update of the panel's other columns
+  // (most of the in-panel flops) rides in the launch of the next diagonal block (diag_update_kernel), so the chain never waits
+  // for it and no second stream is involved.
+  auto panel_chain = [&](int J0, int Wp, int rlim) -> int {
+    int rc = diag_block(J0, nullptr);
+    if (rc) return rc;
+    for (int i = 0; i < Wp; ++i) {
+      const int c = J0 + i;
+      if ((rc = solve_column(c, rlim))) return rc;
+      if (i + 1 >= Wp) break;
+      if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, c, 1, c + 1, 0, 1, rlim))) return rc;
+      const int rest = Wp - i - 2;                             // columns c+2 .. J0+Wp-1
+      if (rest > 0) {
+        GemmArgsT<Real> gu = update_args(c, 1, c + 1, 1, 1 + rest, rlim);
+        gu.r0 *= 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2; gu.patch = 0;
+        rc = diag_block(c + 1, &gu);
+      } else {
+        rc = diag_block(c + 1, nullptr);
+      }
+      if (rc) return rc;
+    }
+    return SIGP_OK;
+  };
+  auto panel_any = [&](int J0, int Wp, int rlim) -> int {
+    return (h->opt_panel_chain && Wp > 2) ? panel_chain(J0, Wp, rlim) : panel_rec(J0, Wp, rlim);
+  };
   // factor block columns [J0, J0+Wp): panel_top = everything on the panel stream up to the strip solve (the whole panel when it
   // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
   auto use_strips = [&](int J0, int Wp) -> bool {
@@ -528,7 +583,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
            (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
   };
   auto panel_top = [&](int J0, int Wp) -> int {
-    if (!use_strips(J0, Wp)) return panel_rec(J0, Wp, R);
+    if (!use_strips(J0, Wp)) return panel_any(J0, Wp, R);
     // panel_mode 1: recursion on the top Wp x Wp block only, then every 128-row strip below it is solved by one
     // workgroup walking the panel's columns (panel_strip_kernel): the lower rows are read and written once
     return panel_rec(J0, Wp, J0 + Wp);
@@ -612,12 +667,31 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     }
     return SIGP_OK;
   }
+  bool have_rest = false;                      // first_on_panel: an update of the rest of the trailing matrix is in flight on su
   for (int J = 0; J < T; J += W) {
     const int Wc = std::min(W, T - J);
     const int ncols = T - (J + Wc);            // trailing column blocks
     if (ncols <= 0) break;
     const int Wn = std::min(W, ncols);         // width of the next panel
-    if (la) {
+    if (la && (h->opt_first_on_panel == 2 || (h->opt_first_on_panel == 1 && !use_strips(J + Wc, Wn)))) {
+      // The update of the NEXT panel's columns stays on the panel stream (stream order, no inter-queue hand-off in the chain
+      // panel -> first update -> next panel: each hand-off is a barrier packet pair, 11-13 us measured); the update stream gets
+      // the rest of the trailing matrix, which the panel stream only has to see finished one panel later.
+      if (have_rest) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_done, 0));   // rest(J - W) wrote these columns too
+      if ((rc = outer(sp, J, Wc, 0, Wn))) return rc;
+      HIPCHK(h, hipEventRecord(s.ev_pan, sp));            // panel J and the first update done: the rest starts behind them, so the
+      HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));     // update the chain waits for has the chip to itself
+      have_rest = ncols > Wn;
+      if (have_rest) {
+        if ((rc = outer(su, J, Wc, Wn, ncols))) return rc;
+        HIPCHK(h, hipEventRecord(s.ev_done, su));
+      }
+      if (h->opt_strips_after_update && use_strips(J + Wc, Wn)) {
+        if ((rc = panel_top(J + Wc, Wn))) return rc;
+        if (have_rest) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_done, 0));
+        if ((rc = panel_strips(J + Wc, Wn))) return rc;
+      } else if ((rc = panel(J + Wc, Wn))) return rc;
+    } else if (la) {
       HIPCHK(h, hipEventRecord(s.ev_pan, sp));            // panel J done
       HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
       rc = outer(su, J, Wc, 0, Wn);                       // next panel's columns first
@@ -637,7 +711,9 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
         if (rc) return rc;
         rc = outer(su, J, Wc, Wn, ncols);
         if (rc) return rc;
+        HIPCHK(h, hipEventRecord(s.ev_done, su));         // (a later panel may take the first_on_panel form and wait for this)
       }
+      have_rest = ncols > Wn;
     } else {
       rc = outer(su, J, Wc, 0, ncols);
       if (rc) return rc;
@@ -1156,6 +1232,8 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "panel_chain")) { h->opt_panel_chain = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
   if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }
