@@ -139,8 +139,10 @@ struct sigp_handle {
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
   int opt_first_on_panel = 1;        // right-looking + look-ahead: the update of the next panel's columns runs on the panel stream: 0 never,
                                      // 1 when that panel is a latency chain (not strip-solved: single fits, small groups), 2 always
-  int opt_panel_chain = 1;           // panels that are not strip-solved (single fits, small groups): right-looking, column by column; only the next
-                                     // column's update is a launch of its own, the other columns' update rides in the diagonal-block launch
+  int opt_panel_chain = 3;           // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
+                                     // own, the other columns' update rides in the diagonal-block launch): bit 0 panels that are not strip-solved (single
+                                     // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion
+  int opt_chain_rows = 160;          // (see panel_any)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
@@ -572,8 +574,12 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     }
     return SIGP_OK;
   };
-  auto panel_any = [&](int J0, int Wp, int rlim) -> int {
-    return (h->opt_panel_chain && Wp > 2) ? panel_chain(J0, Wp, rlim) : panel_rec(J0, Wp, rlim);
+  // top = the top block of a strip-solved panel.  A whole panel takes the chain form only while its riding updates (K = 128, 64x64
+  // tiles: 4 flop per operand byte) stay shorter than the diagonal block they ride beside: up to chain_rows 128-row blocks x
+  // members below the panel's first column (n = 32768 in fp32 is 4 % faster with the recursion's K = 256 / 512 updates)
+  auto panel_any = [&](int J0, int Wp, int rlim, bool top) -> int {
+    const bool chain = Wp > 2 && (top ? (h->opt_panel_chain & 2) != 0 : ((h->opt_panel_chain & 1) != 0 && (long)(rlim - J0) * nb <= h->opt_chain_rows));
+    return chain ? panel_chain(J0, Wp, rlim) : panel_rec(J0, Wp, rlim);
   };
   // factor block columns [J0, J0+Wp): panel_top = everything on the panel stream up to the strip solve (the whole panel when it
   // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
@@ -583,10 +589,10 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
            (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
   };
   auto panel_top = [&](int J0, int Wp) -> int {
-    if (!use_strips(J0, Wp)) return panel_any(J0, Wp, R);
+    if (!use_strips(J0, Wp)) return panel_any(J0, Wp, R, false);
     // panel_mode 1: recursion on the top Wp x Wp block only, then every 128-row strip below it is solved by one
     // workgroup walking the panel's columns (panel_strip_kernel): the lower rows are read and written once
-    return panel_rec(J0, Wp, J0 + Wp);
+    return panel_any(J0, Wp, J0 + Wp, true);
   };
   auto panel_strips = [&](int J0, int Wp) -> int {
     if (!use_strips(J0, Wp)) return SIGP_OK;
@@ -1232,8 +1238,9 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "panel_chain")) { h->opt_panel_chain = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
   if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }

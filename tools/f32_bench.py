@@ -4,11 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import gp_oracle as O
 from seaiceextentforecasting_amd import GPR
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+args = [a for a in sys.argv[1:] if "=" not in a]
+opts = [a.split("=") for a in sys.argv[1:] if "=" in a]      # engine options: name=value
+n = int(args[0]) if args else 32768
 d = 32
 X, y, Xs = O.synthetic_problem(n, d, 20240004, m=1)
 ell, sn = np.sqrt(d), 1e-1
 with GPR(kernel="matern52", dtype="f32") as gp:
+    for k, v in opts:
+        gp.set_option(k, int(v))
     gp.fit(X, y, ell, sn, Xs=Xs)           # warm-up (allocations)
     gp.profile(True); gp.profile_reset()
     t = time.perf_counter(); reps = 3
