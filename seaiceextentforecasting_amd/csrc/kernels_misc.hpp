@@ -18,12 +18,32 @@ struct KParams {
   double sn;        // sigma_n tilde (added on the diagonal)
 };
 
+// exp(x) for the covariance functions (x <= 0, finite): k = rint(x log2 e), r = x - k ln2 (Cody-Waite, ln2 split so that
+// k ln2_hi is exact), degree-13 Taylor polynomial on |r| <= 0.347 (truncation 4e-18), v_ldexp_f64.  <= 2 ulp.  The library
+// exp() costs the build more than its arithmetic: every one of its 64-bit polynomial coefficients is re-materialised with two
+// v_mov_b32 per use (VALU issue slots; the build is VALU-bound: 2.84 ms without its stores, 2.31 ms of stores alone), and it
+// carries overflow / NaN paths that cannot occur here.  The coefficients below sit in a __constant__ table: uniform scalar
+// loads, used as the one scalar operand a v_fma_f64 may take.
+struct ExpCoef { double l2e, ln2hi, ln2lo, c[14]; };
+__constant__ ExpCoef kExpCoef = {1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+                                 {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+                                  1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0}};
+__device__ __forceinline__ double exp_cov(double x) {
+  const double k = __builtin_rint(x * kExpCoef.l2e);
+  double r = fma(-k, kExpCoef.ln2hi, x);
+  r = fma(-k, kExpCoef.ln2lo, r);
+  double p = kExpCoef.c[13];
+#pragma unroll
+  for (int i = 12; i >= 0; --i) p = fma(p, r, kExpCoef.c[i]);
+  return ldexp(p, (int)k);
+}
+
 __device__ inline double cov_from_sq(const KParams& kp, double sq) {
-  if (kp.kernel_id == KID_RBF) return exp(kp.c_rbf * sq);
-  if (kp.kernel_id == KID_RBF_DLOGL) return exp(kp.c_rbf * sq) * sq * (kp.inv_ell * kp.inv_ell);   // k * |d|^2 / l^2
+  if (kp.kernel_id == KID_RBF) return exp_cov(kp.c_rbf * sq);
+  if (kp.kernel_id == KID_RBF_DLOGL) return exp_cov(kp.c_rbf * sq) * sq * (kp.inv_ell * kp.inv_ell);   // k * |d|^2 / l^2
   const double s = sqrt(5.0 * sq) * kp.inv_ell;
-  if (kp.kernel_id == KID_MATERN52_DLOGL) return (s * s * (1.0 / 3.0)) * (1.0 + s) * exp(-s);
-  return (1.0 + s + s * s * (1.0 / 3.0)) * exp(-s);
+  if (kp.kernel_id == KID_MATERN52_DLOGL) return (s * s * (1.0 / 3.0)) * (1.0 + s) * exp_cov(-s);
+  return (1.0 + s + s * s * (1.0 / 3.0)) * exp_cov(-s);
 }
 
 // K5 (north/June1st.py:265 with an RBF / Matern-5/2 covariance in place of X Sigma X^T):
@@ -41,7 +61,7 @@ inline long kbuild_tiles(long n_pad) { const long T = n_pad / KB_TN; return T * 
 template <typename TO>
 struct alignas(4 * sizeof(TO)) KbOut4 { TO v[4]; };
 
-template <typename TO>
+template <typename TO, int DC = KB_DC>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
                                                      const KParams* __restrict__ kps, int flags_in, int colblk0 = 0) {
@@ -64,8 +84,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
   const KParams kp = kps[blockIdx.z];
   X += kp.ds * strideX;
   Mat += blockIdx.z * strideM;
-  __shared__ double Xi[KB_TM][KB_DC + 1];
-  __shared__ __attribute__((aligned(16))) double XjT[KB_DC][KB_TN + 2];
+  __shared__ double Xi[KB_TM][DC + 1];                                    // DC = 8 for d <= 8: 12 KB instead of 50 KB of LDS, so the
+  __shared__ __attribute__((aligned(16))) double XjT[DC][KB_TN + 2];      // CU holds enough workgroups to overlap one's exp() with another's stores
   const int tid = threadIdx.x;
   const int c4 = (tid & 31) * 4, rg = tid >> 5;
   double acc[8][4];
@@ -73,8 +93,8 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
   for (int s = 0; s < 8; ++s)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[s][c] = 0.0;
-  for (int p0 = 0; p0 < d; p0 += KB_DC) {
-    const int pc = min(KB_DC, d - p0);
+  for (int p0 = 0; p0 < d; p0 += DC) {
+    const int pc = min(DC, d - p0);
     __syncthreads();
     // staging: lanes run along the rows, so the transposed image XjT[p][r] is written conflict-free and only the
     // pc live features are touched (the strided 8-byte global reads hit the same lines again for the next p)

@@ -433,7 +433,8 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
   hipStream_t st = stb ? stb : s.s_upd;
   ProfScope ps(h, st, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
   dim3 grid((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb);
-  hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
+  if (d <= 8) hipLaunchKernelGGL((kbuild_kernel<double, 8>), grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
+  else hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
   hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, st, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
