@@ -506,12 +506,13 @@ __global__ void detrend_kernel(const double* __restrict__ data, int P, int T, co
 // fp64 residual of the refinement, with the covariance recomputed on the fly (no n x n fp64 matrix is ever stored):
 //   Rout[r][i] = Bq[r][i] - sum_j ( k~(x_i, x_j) + sn [i==j] ) Xq[r][j]        r < nrhs <= 4, i < n
 // Bq row r is: r == 0 -> y, r >= 1 -> k~(xs_{r-1}, .) (recomputed).  One thread per i (x_i in registers, DREG
-// features), x_j tiles of 64 rows broadcast from LDS.
+// features), x_j tiles of 64 rows broadcast from LDS.  The j range is cut into gridDim.y chunks of jlen columns
+// (krefine_residual_kernel writes the partial sums, krefine_finish_kernel adds them in chunk order and subtracts from Bq): one
+// thread per row alone is 128 workgroups at n = 32768 -- half the CUs idle, one wave per SIMD -- and took 18.3 ms per residual.
 template <int DREG>
-__global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
-                                                               const double* __restrict__ y, int dp, int n, int nrhs,
-                                                               const double* __restrict__ Xq, long ldq, double* __restrict__ Rout,
-                                                               long ldr, KParams kp) {
+__global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __restrict__ X, int dp, int n, int nrhs,
+                                                               const double* __restrict__ Xq, long ldq, double* __restrict__ part,
+                                                               long ldp, int jlen, KParams kp) {
   __shared__ double Xj[64][DREG + 1];
   __shared__ double Q[4][64];
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -519,18 +520,19 @@ __global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __r
 #pragma unroll
   for (int p = 0; p < DREG; ++p) xi[p] = (i < n) ? X[(long)i * dp + p] : 0.0;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int j0 = 0; j0 < n; j0 += 64) {
+  const int jbeg = blockIdx.y * jlen, jend = min(n, jbeg + jlen);
+  for (int j0 = jbeg; j0 < jend; j0 += 64) {
     __syncthreads();
     for (int idx = threadIdx.x; idx < 64 * DREG; idx += 256) {
       const int jj = idx / DREG, p = idx % DREG;
-      Xj[jj][p] = (j0 + jj < n) ? X[(long)(j0 + jj) * dp + p] : 0.0;
+      Xj[jj][p] = (j0 + jj < jend) ? X[(long)(j0 + jj) * dp + p] : 0.0;
     }
     {
       const int r = threadIdx.x >> 6, jj = threadIdx.x & 63;
-      Q[r][jj] = (r < nrhs && j0 + jj < n) ? Xq[(long)r * ldq + j0 + jj] : 0.0;
+      Q[r][jj] = (r < nrhs && j0 + jj < jend) ? Xq[(long)r * ldq + j0 + jj] : 0.0;
     }
     __syncthreads();
-    const int jn = min(64, n - j0);
+    const int jn = min(64, jend - j0);
     for (int jj = 0; jj < jn; ++jj) {
       double sq = 0.0;
 #pragma unroll
@@ -542,18 +544,31 @@ __global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __r
     }
   }
   if (i >= n) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[((long)blockIdx.y * 4 + r) * ldp + i] = acc[r];
+}
+template <int DREG>
+__global__ __launch_bounds__(256) void krefine_finish_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
+                                                             const double* __restrict__ y, int dp, int n, int nrhs,
+                                                             const double* __restrict__ part, long ldp, int nchunk,
+                                                             double* __restrict__ Rout, long ldr, KParams kp) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
   for (int r = 0; r < nrhs; ++r) {
     double b;
     if (r == 0) {
       b = y[i];
     } else {
       const double* xs = Xs + (long)(r - 1) * dp;
+      const double* xi = X + (long)i * dp;
       double sq = 0.0;
 #pragma unroll
       for (int p = 0; p < DREG; ++p) { const double t = xs[p] - xi[p]; sq = fma(t, t, sq); }
       b = cov_from_sq(kp, sq);
     }
-    Rout[(long)r * ldr + i] = b - acc[r];
+    double a = 0.0;
+    for (int c = 0; c < nchunk; ++c) a += part[((long)c * 4 + r) * ldp + i];
+    Rout[(long)r * ldr + i] = b - a;
   }
 }
 

@@ -81,6 +81,7 @@ struct sigp_handle {
   float* fXw = nullptr;                      // [4][n_pad] second working row set of those solves
   double* xq = nullptr;      // [4][n_pad] refined solutions: row 0 alpha~ = K~^-1 y, rows 1..m  w_j = K~^-1 k~*_j
   double* rq = nullptr;      // [4][n_pad] fp64 residuals
+  double* rpart = nullptr;   // [REFINE_CHUNKS][4][n_pad] partial sums of a residual (krefine_residual_kernel)
   double* fpart = nullptr;   // partial sums of the final dots
   int opt_refine_iters = 3;
   double refine_resid = 0;   // ||y - K~ alpha~||_inf / ||y||_inf after the last refinement step
@@ -922,12 +923,13 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* din
 // ---- fp32 engine: fp32 kernel matrix + Cholesky, fp64 iterative refinement of alpha~ and w_j -----------------
 // (BASELINE configs[4]; no reference counterpart -- the reference is fp64 NumPy.  Same outputs as the fp64 path:
 //  sigma_f, nlML, mean, var of north/June1st.py:267-277, 246.)
+constexpr int REFINE_CHUNKS = 64;
 int f32_reserve(sigp_handle* h, long n_pad, int G = 1) {
   if (h->cap_f_npad >= n_pad && h->cap_f_G >= G) return SIGP_OK;
   n_pad = std::max(n_pad, h->cap_f_npad); G = std::max(G, h->cap_f_G);
   HIPCHK(h, hipDeviceSynchronize());
   for (float** p : {&h->fmat, &h->fdinv, &h->fZ, &h->fU, &h->fV, &h->fXw}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-  for (double** p : {&h->xq, &h->rq, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
+  for (double** p : {&h->xq, &h->rq, &h->rpart, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
   h->cap_f_npad = 0; h->cap_f_G = 0;
   // G lockstep members of the factor (batch path); the solve / refinement workspaces below serve one member at a time
   HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)G * (n_pad + RIDE) * n_pad * sizeof(float)));
@@ -939,6 +941,7 @@ int f32_reserve(sigp_handle* h, long n_pad, int G = 1) {
   HIPCHK(h, hipMalloc((void**)&h->fXw, (size_t)TS_RHS * n_pad * sizeof(float)));
   HIPCHK(h, hipMalloc((void**)&h->xq, (size_t)4 * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->rq, (size_t)4 * n_pad * sizeof(double)));
+  HIPCHK(h, hipMalloc((void**)&h->rpart, (size_t)REFINE_CHUNKS * 4 * n_pad * sizeof(double)));
   HIPCHK(h, hipMalloc((void**)&h->fpart, (size_t)(n_pad / 256 + 1) * 8 * sizeof(double)));
   HIPCHK(h, hipDeviceSynchronize());
   h->cap_f_npad = n_pad; h->cap_f_G = G;
@@ -1056,11 +1059,19 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
     HIPCHK(h, hipGetLastError());
   }
   const unsigned nblk = (unsigned)((n + 255) / 256);
+  // the columns of a residual in chunks, so that the launch fills the chip (~8 workgroups per CU): chunk length a multiple of 64
+  const int want = (int)std::min<long>(REFINE_CHUNKS, std::max<long>(1, 2048 / nblk));
+  const int jlen = (int)(((n + want - 1) / want + 63) / 64 * 64);
+  const unsigned nchunk = (unsigned)((n + jlen - 1) / jlen);
   for (int it = 0; it <= h->opt_refine_iters; ++it) {
     // r = b - K~ x in fp64, covariance recomputed on the fly
-#define CALL_RES(D) hipLaunchKernelGGL(krefine_residual_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->rq, ld, kp)
+#define CALL_RES(D) hipLaunchKernelGGL(krefine_residual_kernel<D>, dim3(nblk, nchunk), dim3(256), 0, st, X, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->rpart, ld, jlen, kp)
     SIGP_DREG_DISPATCH(d, CALL_RES);
 #undef CALL_RES
+    HIPCHK(h, hipGetLastError());
+#define CALL_FIN(D) hipLaunchKernelGGL(krefine_finish_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->rpart, ld, (int)nchunk, h->rq, ld, kp)
+    SIGP_DREG_DISPATCH(d, CALL_FIN);
+#undef CALL_FIN
     HIPCHK(h, hipGetLastError());
     if (it == h->opt_refine_iters) break;    // the last pass only measures the residual
     const long tot = (long)nrhs * n_pad;
@@ -1183,7 +1194,7 @@ int sigp_destroy(sigp_handle* h) {
   (void)hipDeviceSynchronize();
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
-  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->rpart, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
   if (h->dl.mat) (void)hipFree(h->dl.mat);
   if (h->dl.dinv) (void)hipFree(h->dl.dinv);
   for (auto e : h->dl.ev_buf) if (e) (void)hipEventDestroy(e);
