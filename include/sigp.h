@@ -242,7 +242,7 @@ int sigp_profile_reset(sigp_handle* h);
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it)
  *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [3] (bit 0: panels that are not strip-solved,
  *   bit 1: top blocks of strip-solved panels, are factored column by column with the other columns' update riding in the diagonal-block
- *   launch; 0 = binary recursion), chain_rows [160] (bit 0 applies while rows-below x members <= this), first_on_panel [1] (the update of
+ *   launch; 0 = binary recursion), chain_rows [80] (bit 0 applies while rows-below x members <= this), first_on_panel [1] (the update of
  *   the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always)
  *   pan_priority, diag_prio, patch, reserve_cus, host_timing   measurement switches; c_dma, syrk_v2: libsigp_debug.so only */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);

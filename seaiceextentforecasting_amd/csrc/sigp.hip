@@ -143,7 +143,7 @@ struct sigp_handle {
   int opt_panel_chain = 3;           // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
                                      // own, the other columns' update rides in the diagonal-block launch): bit 0 panels that are not strip-solved (single
                                      // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion
-  int opt_chain_rows = 160;          // (see panel_any)
+  int opt_chain_rows = 80;           // (see panel_any)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
@@ -577,7 +577,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     return SIGP_OK;
   };
   // top = the top block of a strip-solved panel.  A whole panel takes the chain form only while its riding updates (K = 128, 64x64
-  // tiles: 4 flop per operand byte) stay shorter than the diagonal block they ride beside: up to chain_rows 128-row blocks x
+  // tiles: 4 flop per operand byte) stay shorter than the diagonal block they ride beside: up to chain_rows (80) 128-row blocks x
   // members below the panel's first column (n = 32768 in fp32 is 4 % faster with the recursion's K = 256 / 512 updates)
   auto panel_any = [&](int J0, int Wp, int rlim, bool top) -> int {
     const bool chain = Wp > 2 && (top ? (h->opt_panel_chain & 2) != 0 : ((h->opt_panel_chain & 1) != 0 && (long)(rlim - J0) * nb <= h->opt_chain_rows));
