@@ -63,7 +63,8 @@ struct sigp_handle {
   double* X = nullptr;  long cap_X = 0;       // [n_pad][dp]
   double* y = nullptr;  long cap_y = 0;       // [n_pad]
   double* Xs = nullptr; long cap_Xs = 0;      // [128][dp] ride-along test rows (row j = test point j)
-  double* scratchZ = nullptr; long cap_Z = 0; // [128][n_pad] second ride block (predict / alpha)
+  double* scratchZ = nullptr; long cap_Z = 0; // [128][n_pad] second ride block (predict / alpha); predict with many points: up to 16 of them
+  KParams* pred_kps = nullptr;                // chunk parameters of a prediction group
   double* T = nullptr; long cap_T = 0;        // reference kernel: X Sigma~ [n_pad][dp]
   double* Sig = nullptr; long cap_Sig = 0;    // Sigma~ padded [dp][dp]
   double* XsA = nullptr;                      // [128][dp] ride rows shifted by one (row 0 = 0) for the GEMM-form build
@@ -1200,6 +1201,7 @@ int sigp_destroy(sigp_handle* h) {
   for (auto e : h->dl.ev_buf) if (e) (void)hipEventDestroy(e);
   if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
   if (h->sm_probs) (void)hipFree(h->sm_probs);
+  if (h->pred_kps) (void)hipFree(h->pred_kps);
   if (h->fmat) (void)hipFree(h->fmat);
   if (h->fdinv) (void)hipFree(h->fdinv);
   if (h->fZ) (void)hipFree(h->fZ);
@@ -1624,6 +1626,46 @@ int sigp_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, doub
   double* xs_dev = h->stage + xs_off;
   hipStream_t st = s.s_upd;
   const double* z = s.mat + n_pad * ld;   // solved row 0 of the ride block: z = L~^-1 y
+  if (h->kernel_id != SIGP_KERNEL_NETDIFFUSION && m > RIDE) {
+    // Many test points: groups of up to PRED_CHUNKS 128-row chunks advance through the forward solve in lockstep (one launch
+    // per block column for the whole group instead of one per chunk: the solve becomes MFMA work instead of a latency chain of
+    // 2 T launches per 128 points), one host synchronisation per group.
+    constexpr int PRED_CHUNKS = 16;
+    const long gmax = std::min<long>(PRED_CHUNKS, (m + RIDE - 1) / RIDE);
+    if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, gmax * RIDE * n_pad))) return rc;
+    const long raw = gmax * RIDE * std::max<long>(ldxs, dp);          // stage = [raw group | padded group [gmax*128][dp] | results [gmax][512]]
+    if ((rc = ensure(h, &h->stage, &h->cap_stage, raw + gmax * RIDE * dp + gmax * 512))) return rc;
+    double* xs_grp = h->stage + raw;
+    double* res_grp = xs_grp + gmax * RIDE * dp;
+    if (!h->pred_kps) HIPCHK(h, hipMalloc((void**)&h->pred_kps, PRED_CHUNKS * sizeof(KParams)));
+    std::vector<KParams> kpc((size_t)gmax, h->kp);
+    for (long c = 0; c < gmax; ++c) kpc[(size_t)c].ds = (int)c;       // "data set" c = chunk c of the padded group (strideXs below)
+    HIPCHK(h, hipMemcpyAsync(h->pred_kps, kpc.data(), (size_t)gmax * sizeof(KParams), hipMemcpyHostToDevice, st));
+    std::vector<double> res_host((size_t)gmax * 512);
+    for (long c0 = 0; c0 < m; c0 += gmax * RIDE) {
+      const long mg = std::min<long>(gmax * RIDE, m - c0);
+      const int nch = (int)((mg + RIDE - 1) / RIDE);
+      HIPCHK(h, hipMemcpyAsync(h->stage, Xs + c0 * ldxs, (size_t)((mg - 1) * ldxs + h->d) * sizeof(double), hipMemcpyHostToDevice, st));
+      const long tot = (long)nch * RIDE * dp;
+      hipLaunchKernelGGL(pad_copy_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->stage, (long)ldxs, (int)mg, (int)h->d, xs_grp, nch * RIDE, (int)dp);
+      HIPCHK(h, hipGetLastError());
+      hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nch), dim3(256), 0, st, h->X, 0L, xs_grp, (long)RIDE * dp,
+                         (const double*)nullptr, 0L, (int)dp, (int)h->d, (int)n, (int)n_pad, (int)RIDE, 0, h->scratchZ, (long)RIDE * ld, ld, h->pred_kps, 1);
+      HIPCHK(h, hipGetLastError());
+      if ((rc = solve_rows_forward(h, s, h->scratchZ, n_pad, nch))) return rc;
+      hipLaunchKernelGGL(epilogue_kernel<double>, dim3((unsigned)(RIDE + 1), (unsigned)nch), dim3(256), 0, st, h->scratchZ, ld, z, (const double*)nullptr, ld, (int)n,
+                         (int)n_pad, (int)RIDE, res_grp, (long)RIDE * ld, 0L, 0L);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(res_host.data(), res_grp, (size_t)nch * 512 * sizeof(double), hipMemcpyDeviceToHost, st));
+      HIPCHK(h, hipStreamSynchronize(st));
+      for (long j = 0; j < mg; ++j) {
+        const double* rj = res_host.data() + (j / RIDE) * 512;
+        mean[c0 + j] = rj[j % RIDE];
+        var[c0 + j] = h->sigma_f * (1.0 + h->sn_tilde - rj[128 + j % RIDE]);
+      }
+    }
+    return SIGP_OK;
+  }
   std::vector<double> xs_host((size_t)RIDE * dp);
   for (long c0 = 0; c0 < m; c0 += RIDE) {
     const long mc = std::min<long>(RIDE, m - c0);

@@ -357,6 +357,24 @@ def test_panel_chain_and_first_update_placement_are_schedules_only(S, dtype):
         assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[2][k], res[3][k]), k
 
 
+@pytest.mark.parametrize("kind", ["rbf", "matern52"])
+def test_predict_many_points_in_lockstep_groups(S, kind):
+    """north/June1st.py:272-277 for many test points: more than 128 points go through the forward solve in groups of up to 16
+    chunks advancing in lockstep (sigp_predict).  Same numbers as chunk-by-chunk prediction (bit-identical: a chunk's rows
+    never mix with another's) and as the oracle; a ragged last chunk and a ragged last group included."""
+    n, d, m = 1500, 6, 16 * 128 + 300
+    X, y, _ = O.synthetic_problem(n, d, 4242, m=1)
+    Xs = np.random.default_rng(7).standard_normal((m, d))
+    with S.GPR(kernel=kind) as gp:
+        gp.fit(X, y, 2.0, 5e-2)
+        mu, var = gp.predict(Xs)
+        mu1 = np.concatenate([gp.predict(Xs[i:i + 128])[0] for i in range(0, m, 128)])
+        var1 = np.concatenate([gp.predict(Xs[i:i + 128])[1] for i in range(0, m, 128)])
+    assert np.array_equal(mu, mu1) and np.array_equal(var, var1)
+    ref = O.fit_predict(X, y, Xs, 2.0, 5e-2, kind=kind, ref_idiom=False)
+    assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= TOL_PRED
+
+
 def test_diagonal_block_kernel_reports_the_first_bad_pivot(S):
     """np.linalg.cholesky raises on the first non-positive pivot (north/June1st.py:265 inside MLII's try): the diagonal-block
     kernel keeps LAPACK's info = 1-based index of that pivot, whichever 16-column step, pivot wave or block it falls in."""
