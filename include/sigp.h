@@ -232,7 +232,7 @@ int sigp_profile_reset(sigp_handle* h);
  *   panel_ll [0]          panels up to this width are factored left-looking inside
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
- *   refine_iters [3]      fp32 engine: fp64 refinement steps
+ *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
  *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack / _local_update return without a host sync (see sigp_dist_sync)
  *   owner_only [0]        sigp_set_train does not allocate the n x n slot matrix (sigp_dist_local_*)
  *   tile walks of the trailing update -- placement only, results bit-identical; all measured slower than the default and left off

@@ -85,6 +85,7 @@ struct sigp_handle {
   double* rpart = nullptr;   // [REFINE_CHUNKS][4][n_pad] partial sums of a residual (krefine_residual_kernel)
   double* fpart = nullptr;   // partial sums of the final dots
   int opt_refine_iters = 3;
+  int opt_refine_tol_e = 12; // stop refining once every residual is below 10^-this (relative); 0 = always refine_iters steps
   double refine_resid = 0;   // ||y - K~ alpha~||_inf / ||y||_inf after the last refinement step
   std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
   std::vector<double> fit_res;                // epilogue reductions of the last fit (host copy)
@@ -1064,6 +1065,7 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
   const int want = (int)std::min<long>(REFINE_CHUNKS, std::max<long>(1, 2048 / nblk));
   const int jlen = (int)(((n + want - 1) / want + 63) / 64 * 64);
   const unsigned nchunk = (unsigned)((n + jlen - 1) / jlen);
+  double ymax_dev = -1.0;
   for (int it = 0; it <= h->opt_refine_iters; ++it) {
     // r = b - K~ x in fp64, covariance recomputed on the fly
 #define CALL_RES(D) hipLaunchKernelGGL(krefine_residual_kernel<D>, dim3(nblk, nchunk), dim3(256), 0, st, X, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->rpart, ld, jlen, kp)
@@ -1075,6 +1077,26 @@ int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const doubl
 #undef CALL_FIN
     HIPCHK(h, hipGetLastError());
     if (it == h->opt_refine_iters) break;    // the last pass only measures the residual
+    if (h->opt_refine_tol_e > 0 && it > 0) {
+      // converged already?  (every right-hand side: y against max|y|, the unit-variance cross-covariances against 1)  Then this
+      // residual is the final measurement: one residual + one solve pair saved on every well-conditioned fit
+      std::vector<double> rr((size_t)nrhs * n);
+      for (int r = 0; r < nrhs; ++r) HIPCHK(h, hipMemcpyAsync(rr.data() + (size_t)r * n, h->rq + (size_t)r * ld, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+      if (ymax_dev < 0) {
+        std::vector<double> yh0((size_t)n);
+        HIPCHK(h, hipMemcpyAsync(yh0.data(), y, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipStreamSynchronize(st));
+        ymax_dev = 0; for (long i = 0; i < n; ++i) ymax_dev = std::max(ymax_dev, std::fabs(yh0[i]));
+      } else {
+        HIPCHK(h, hipStreamSynchronize(st));
+      }
+      double worst = 0;
+      for (int r = 0; r < nrhs; ++r) {
+        double mx = 0; for (long i = 0; i < n; ++i) mx = std::max(mx, std::fabs(rr[(size_t)r * n + i]));
+        worst = std::max(worst, r == 0 ? (ymax_dev > 0 ? mx / ymax_dev : 0.0) : mx);
+      }
+      if (worst <= std::pow(10.0, -(double)h->opt_refine_tol_e)) break;
+    }
     const long tot = (long)nrhs * n_pad;
     hipLaunchKernelGGL((convert_rows_kernel<double, float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)h->rq, ld, h->fZ, ld,
                        nrhs, (int)n_pad, (int)n);
@@ -1232,6 +1254,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     }
     return SIGP_OK;
   }
+  if (!strcmp(name, "refine_tol_e")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_refine_tol_e = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
