@@ -26,12 +26,12 @@ json.dump(out, open("profiles/%s_pmc_syrk128.json" % rnd, "w"), indent=1)
 print(out["launches"], "fetch GB %.3f write GB %.3f busy %.3f" % (out["fetch_bytes_per_launch_corrected"] / 1e9, out["write_bytes_per_launch"] / 1e9, out["mfma_pipe_busy_fraction"]))
 
 # the covariance build (north_star: "rocprof achieved-HBM-GB/s on the kernel build"): PMC bytes of the same passes / rocprofv3 --stats duration
-selk = lambda df: df[df["Kernel_Name"].str.contains("kbuild_kernel<double>", regex=False)]
+selk = lambda df: df[df["Kernel_Name"].str.contains("kbuild_kernel<double", regex=False)]
 fk = selk(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
 wk = selk(pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv"))
 st = pd.read_csv(base + "stats/bench_kernel_stats.csv")
-st = st[st["Name"].str.contains("kbuild_kernel<double>", regex=False)]
-kb = {"kernel": "sigp::kbuild_kernel<double> (RBF covariance build of 40 lockstep members, lower 64x128 tiles, n = 8192, d = 8)",
+st = st[st["Name"].str.contains("kbuild_kernel<double", regex=False)]
+kb = {"kernel": "sigp::kbuild_kernel<double, 8> (RBF covariance build of 40 lockstep members, lower 64x128 tiles, n = 8192, d = 8)",
       "launches_pmc": int(len(wk)), "write_bytes_per_launch": float(wk["Counter_Value"].mean()) * 1024,
       "fetch_bytes_per_launch_corrected": float(fk["Counter_Value"].mean()) * 1024 * 2,
       "algorithmic_bytes_per_launch": 40 * (4.0 * 8192 * 8193 + 8.0 * 8192 * 8),
