@@ -375,6 +375,19 @@ def test_predict_many_points_in_lockstep_groups(S, kind):
     assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= TOL_PRED
 
 
+def test_randomised_fits_against_the_oracle(S):
+    """60 seeded random single fits (orders on and around the 16 / 128 / 1024 block boundaries, 1..40 features, 0..4 ride rows,
+    both covariances, fp64 and fp32, outer panel widths 1..16, every panel / first-update schedule, look-ahead on and off)
+    against the oracle: fp64 within 1e-8 (mean, variance, sigma_f) / 1e-9 (nlML), fp32 within its stated tolerances
+    (tools/fuzz_fits.py; 500 cases of it ran clean while the round's kernels were written)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_fits", os.path.join(ROOT, "tools", "fuzz_fits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fails, worst = mod.run(60, 20241004, verbose=False)
+    assert fails == 0, worst
+
+
 def test_diagonal_block_kernel_reports_the_first_bad_pivot(S):
     """np.linalg.cholesky raises on the first non-positive pivot (north/June1st.py:265 inside MLII's try): the diagonal-block
     kernel keeps LAPACK's info = 1-based index of that pivot, whichever 16-column step, pivot wave or block it falls in."""
