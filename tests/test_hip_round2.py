@@ -386,6 +386,10 @@ def test_randomised_fits_against_the_oracle(S):
     spec.loader.exec_module(mod)
     fails, worst = mod.run(60, 20241004, verbose=False)
     assert fails == 0, worst
+    # lockstep batches: 1..4 data sets x 2..10 fits in groups of 1..F (ragged last group), strips forced on small shapes, a
+    # singular member now and then (150 cases of it ran clean)
+    fails, worst = mod.run_batches(15, 20241005, verbose=False)
+    assert fails == 0, worst
 
 
 def test_diagonal_block_kernel_reports_the_first_bad_pivot(S):

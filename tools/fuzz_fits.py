@@ -48,6 +48,50 @@ def run(cases, seed, verbose=True):
   return fails, worst
 
 
+def run_batches(cases, seed, verbose=True):
+  """Lockstep batches: B data sets x F fits in groups of G (ragged last group), strips forced on small shapes through strip_min,
+  chain / recursion top blocks, one member made singular now and then (its info > 0, the others untouched)."""
+  rng = np.random.default_rng(seed)
+  fails = 0; worst = 0.0; t0 = time.time()
+  for case in range(cases):
+      n = int(rng.integers(100, 1700)); d = int(rng.integers(1, 12)); B = int(rng.integers(1, 5)); F = int(rng.integers(2, 11))
+      G = int(rng.integers(1, F + 1)); W = int(rng.choice([2, 4, 8]))
+      kind = str(rng.choice(["rbf", "matern52"]))
+      Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+      for b in range(B):
+          Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 5000 + 10 * case + b, m=1)
+      ell = np.sqrt(d) * 10 ** rng.uniform(-0.4, 0.4, F); sn = 10 ** rng.uniform(-2, 0, F)
+      bad = int(rng.integers(0, F)) if (rng.random() < 0.3 and n > 40) else -1
+      if bad >= 0:
+          Xb[bad % B, n // 2] = Xb[bad % B, n // 3]; sn[bad] = 0.0      # duplicate row + no noise: K~ singular for every fit of that data set with sn~ = 0
+      opts = {"panel_chain": int(rng.choice([0, 1, 3])), "strip_min": int(rng.choice([1, 8, 512])), "first_on_panel": int(rng.choice([0, 1, 2]))}
+      with GPR(kernel=kind, outer_blocks=W, panel_mode=str(rng.choice(["auto", "strips", "recursive"]))) as gp:
+          for k, v in opts.items():
+              gp.set_option(k, v)
+          r = gp.fit_batch(Xb, yb, Xsb, ell, sn, concurrency=int(rng.choice([1, 2])), group=G)
+      for i in range(F):
+          b = i % B
+          if i == bad:
+              continue        # singular to rounding: either outcome (info > 0 or a huge condition number) is legitimate
+          ref = O.fit_predict(Xb[b], yb[b], Xsb[b], float(ell[i]), float(sn[i]), kind=kind, ref_idiom=False)
+          errs = [abs(r["mean"][i, 0] - ref["fmean"][0]) / abs(ref["fmean"][0]), abs(r["var"][i, 0] - ref["fvar"][0]) / abs(ref["fvar"][0]),
+                  abs(r["nlml"][i] - ref["nlml"]) / abs(ref["nlml"])]
+          cond_ok = sn[i] > 0 or bad < 0 or (i % B) != (bad % B)
+          e = max(errs)
+          if cond_ok:
+              worst = max(worst, e)
+          if r["info"][i] != 0 or not (e <= (1e-8 if cond_ok else 1e-2)):
+              if cond_ok or r["info"][i] == 0:
+                  fails += 1
+                  print("FAIL batch case %d fit %d: n=%d d=%d B=%d F=%d G=%d W=%d %s %s info=%d err %.3e" % (case, i, n, d, B, F, G, W, kind, opts, r["info"][i], e), flush=True)
+  if verbose:
+    print("%d batch cases in %.1f s, %d failures; worst relative error %.1e" % (cases, time.time() - t0, fails, worst))
+  return fails, worst
+
+
 if __name__ == "__main__":
-    f, _ = run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
-    sys.exit(1 if f else 0)
+    nc = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    sd = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+    f, _ = run(nc, sd)
+    f2, _ = run_batches(max(1, nc // 5), sd + 1)
+    sys.exit(1 if (f or f2) else 0)
