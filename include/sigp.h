@@ -139,6 +139,21 @@ int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, in
  * out [A][T] = sum over the area's pixels of data * weight (NaN products as 0), pixels added in ascending order. */
 int sigp_area_sums(sigp_handle* h, const double* data, int64_t P, int64_t T, const double* weight, const int32_t* label, int64_t A, double* out);
 
+/* ComplexNetworks.Network.area_level (ComplexNetworks.py:49-281) on the HOST (sequential greedy region growing + merging; no
+ * handle, no GPU): the same decisions as the reference, in the same order, on means formed in np.nanmean's summation order, so the
+ * areas are identical (csrc/area_level.cpp).  R [N][N]: the cell-to-cell correlations (NaN on the diagonal) of the N active cells;
+ * node_of_cell [dimX*dimY]: row of R of a grid cell (row-major), -1 for an inactive one; cell_nan: flat index of the first NaN
+ * cell of the data (the reference's out-of-bounds sentinel); tau: the threshold of sigp_corr_tau; latlon != 0: left / right
+ * neighbours wrap.  Outputs (caller-allocated, N entries each, area_offsets N + 1): the areas in the reference's dict order --
+ * area_ids[a] = its key, cells_out[area_offsets[a] .. area_offsets[a+1]) = its cells (flat indices) in list order -- and the
+ * cells set aside by the merging step, in order (Network.unavail): at most unavail_cap of them are written, *n_unavail_out is the
+ * full length (it can exceed N on a lat-lon grid; call again with a larger buffer then). */
+int sigp_area_level(const double* R, int64_t N, const int32_t* node_of_cell, int64_t dimX, int64_t dimY, int32_t cell_nan, double tau,
+                    int latlon, int32_t* cells_out, int64_t* area_offsets, int32_t* area_ids, int64_t* n_areas_out, int32_t* unavail_out,
+                    int64_t unavail_cap, int64_t* n_unavail_out);
+/* np.nanmean of a contiguous array in NumPy's own summation order (what sigp_area_level decides on; exported for its test) */
+double sigp_host_nanmean(const double* a, int64_t n);
+
 /* The step before the feature pipeline: detrend() of north/June1st.py:179-194 (one cut: cut_len = {T}) and of the retro
  * scripts (north/retrospective_forecasts/June1st_retro.py:178-195: one detrended cube per cut-off year) in ONE launch.
  * data [P][T] pixel-major anomaly series; cut c removes the least-squares line (scipy.stats.linregress semantics, NaN propagating)
