@@ -320,16 +320,18 @@ def significant_positive_mean(R, dof, significance):
     return np.mean(positive[significant])
 
 
-def networks(dataset, latlon=False, area_key="psar", lat_key="lat", significance=0.01):
+def networks(dataset, latlon=False, area_key="psar", lat_key="lat", significance=0.01, engine=None):
     """The scripts' ``networks()`` driver (north/June1st.py:196-206): sets ``dataset['nodes']`` and
-    ``dataset['anoms']`` from ``dataset['dt']``."""
+    ``dataset['anoms']`` from ``dataset['dt']``.  ``engine``: a ``GPR`` handle -- the correlation matrix / threshold and the area
+    sums are then formed on the GPU (``Network.tau(engine=)``, ``Network.intra_links(engine=)``); the areas come from the C++
+    ``sigp_area_level`` either way."""
     net = Network(data=dataset["dt"])
-    Network.tau(net, significance)
+    Network.tau(net, significance, engine=engine)
     Network.area_level(net, latlon_grid=latlon)
     if latlon:
-        Network.intra_links(net, lat=dataset[lat_key])
+        Network.intra_links(net, lat=dataset[lat_key], engine=engine)
     else:
-        Network.intra_links(net, area=dataset[area_key])
+        Network.intra_links(net, area=dataset[area_key], engine=engine)
     dataset["nodes"] = net.V
     dataset["anoms"] = net.anomaly
     return net
