@@ -9,7 +9,7 @@ from .features import (SCRIPT_TABLE, LGRID, SGRID, select_features, design_matri
 from .retro import retro_forecast, operational_forecast, retro_grid_search  # noqa: F401
 from .smallbatch import SmallBatch  # noqa: F401
 from .callers import detrend, detrend_cube, skill, forecast_tables  # noqa: F401
-from .networks import Network  # noqa: F401  (the scripts' networks() driver lives at seaiceextentforecasting_amd.networks.networks)
+from .networks import Network, networks_retro  # noqa: F401  (the scripts' networks() driver lives at seaiceextentforecasting_amd.networks.networks)
 from .dist import shard_indices, gather_results, fit_batch_sharded, DistributedGPR  # noqa: F401
 
 __all__ = ["GPR", "LinAlgError", "SCRIPT_TABLE", "LGRID", "SGRID", "select_features", "design_matrix",

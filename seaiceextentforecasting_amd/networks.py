@@ -335,3 +335,19 @@ def networks(dataset, latlon=False, area_key="psar", lat_key="lat", significance
     dataset["nodes"] = net.V
     dataset["anoms"] = net.anomaly
     return net
+
+
+def networks_retro(dataset, fmin, fmax, latlon=False, area_key="psar", lat_key="lat", significance=0.01, engine=None):
+    """The retro scripts' ``networks(dataset, fmin, fmax)`` (north/retrospective_forecasts/September1st_retro.py:161-169): one
+    network per forecast year on ``dataset['dt_YYYY']`` -> ``dataset['nodes_YYYY']``, ``dataset['anoms_YYYY']``."""
+    for year in range(fmin, fmax + 1):
+        net = Network(data=dataset["dt_%d" % year])
+        Network.tau(net, significance, engine=engine)
+        Network.area_level(net, latlon_grid=latlon)
+        if latlon:
+            Network.intra_links(net, lat=dataset[lat_key], engine=engine)
+        else:
+            Network.intra_links(net, area=dataset[area_key], engine=engine)
+        dataset["nodes_%d" % year] = net.V
+        dataset["anoms_%d" % year] = net.anomaly
+    return dataset

@@ -718,3 +718,44 @@ def test_networks_driver_on_the_device_matches_the_host_driver(S):
     assert list(host["nodes"]) == list(dev["nodes"]) and host["nodes"] == dev["nodes"]
     for k in host["anoms"]:
         assert np.array_equal(host["anoms"][k], dev["anoms"][k]), k
+
+
+def test_retro_run_end_to_end_device_pipeline_equals_host_pipeline(S):
+    """The retro scripts' main sequence (September1st_retro.py:295-299: detrend -> networks -> forecast -> skill) on synthetic
+    inputs of the real shape (57 x 57 grid, three regions), once with detrending / tau / area sums on the GPU and once on the
+    host (areas from sigp_area_level both times, the GP batch on the GPU both times): the same `.round(3)` forecasts and skills."""
+    import seaiceextentforecasting_amd.networks as NW
+    from scipy.stats import linregress
+    fmin, fmax = 1992, 1996
+    T = fmax - 1979 + 1
+    rng = np.random.default_rng(2024)
+    base = np.cumsum(rng.standard_normal((6, T)), axis=1) * 0.3 + rng.standard_normal((6, T))
+    sic = np.full((57, 57, T), np.nan)
+    for i in range(57):
+        for j in range(57):
+            if (i - 28) ** 2 + (j - 28) ** 2 < 26 ** 2:
+                sic[i, j] = 0.5 + 0.1 * base[(i // 20) * 2 + (j // 30)] + 0.07 * rng.standard_normal(T) - 0.002 * np.arange(T)
+    psar = rng.uniform(0.8, 1.2, (57, 57))
+    regions = ["Pan-Arctic", "Beaufort", "Chukchi"]
+    SIEs, SIEs_dt, SIEs_trend = {}, {}, {}
+    for r, scale in zip(regions, (6.0, 0.6, 0.5)):
+        SIEs[r] = (scale - 0.01 * scale * np.arange(T) + 0.05 * scale * (base[regions.index(r)] + rng.standard_normal(T))).round(3)
+        trend = np.zeros((fmax - (fmin - 1) + 1, 2)); dt = np.zeros((fmax - (fmin - 1) + 1, T))
+        for year in range(fmin - 1, fmax + 1):
+            n = year - 1979 + 1
+            reg = linregress(np.arange(n), SIEs[r][:n])
+            trend[year - (fmin - 1)] = reg[0], reg[1]
+            dt[year - (fmin - 1), :n] = SIEs[r][:n] - (reg[0] * np.arange(n) + reg[1])
+        SIEs_trend[r], SIEs_dt[r] = trend, dt.round(3)
+    outs = []
+    with S.GPR(kernel="netdiffusion") as gp:
+        for eng in (None, gp):
+            SIC = {"data": sic.copy(), "psar": psar}
+            S.detrend(SIC, fmin, fmax, engine=eng)
+            NW.networks_retro(SIC, fmin, fmax, engine=eng)
+            out = S.retro_forecast("north_September", SIC, SIEs_dt, SIEs_trend, fmin, fmax, gp=gp, batched=True)
+            outs.append((out, S.skill(out, SIEs, SIEs_dt, fmin, fmax, regions), {k: v for k, v in SIC.items() if k.startswith("nodes_")}))
+    assert outs[0][2] == outs[1][2]                                   # the same areas every year
+    for k in outs[0][0]:
+        assert np.array_equal(outs[0][0][k], outs[1][0][k]), k
+    assert outs[0][1][0] == outs[1][1][0] and outs[0][1][1] == outs[1][1][1]
