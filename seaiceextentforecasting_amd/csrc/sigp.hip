@@ -760,7 +760,71 @@ int dist_update(sigp_handle* h, Real* Mm, hipStream_t st, long n_pad, int kcol0,
 // Mm = (virtual) origin of the storage the panel's columns live in, row stride ld: the slot's square matrix (ld = n_pad) or one
 // rank's block columns (sigp_dist_local_*: ld = its column count, origin shifted so that GLOBAL column indices land in it)
 template <typename Real>
+int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp);
+// the panel in its latency-chain form (potrf_core's panel_chain, one member): right-looking column by column, the update of the
+// columns beyond the next one riding in the next diagonal block's launch.  Same k order per tile as the recursion: bit-identical.
+template <typename Real>
 int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
+  const int T = (int)(n_pad / NB), R = T + 1;
+  if (!(h->opt_panel_chain & 1) || Wp <= 2 || (long)(R - J0) > h->opt_chain_rows) return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, Wp);
+  constexpr int diag_lds = diag_lds_bytes<Real>();
+  constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());
+  static AttrOnce du_attr, d_attr;
+  HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
+  HIPCHK(h, d_attr.set(h->device, (const void*)potrf_diag_kernel<Real>, diag_lds));
+  auto upd_args = [&](int kc, int ccol0, int c0, int c1) {
+    const long o = (long)ccol0 * NB;
+    GemmArgsT<Real> g{};
+    g.A = Mm + o * ld + (long)kc * NB; g.lda = ld;
+    g.B = g.A; g.ldb = ld;
+    g.C = Mm + o * ld + o; g.ldc = ld;
+    g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1;
+    return g;
+  };
+  auto diag = [&](int c, const GemmArgsT<Real>* gu) -> int {
+    Real* Ac = Mm + (long)c * NB * ld + (long)c * NB;
+    const int ntile = gu ? gemm_grid_size(gu->r0, gu->r1, gu->c0, gu->c1, 1, 0) : 0;
+    if (ntile > 0) {
+      const int wgs = (ntile + 1) / 2;
+      hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(1 + wgs), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L, 1,
+                         *gu, ntile, wgs);
+    } else {
+      hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(1), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
+    }
+    HIPCHK(h, hipGetLastError());
+    return SIGP_OK;
+  };
+  int rc = diag(J0, nullptr);
+  if (rc) return rc;
+  for (int i = 0; i < Wp; ++i) {
+    const int c = J0 + i;
+    const long o = (long)(c + 1) * NB;
+    const int rows_below = R - (c + 1);
+    if (rows_below > 0) {
+      GemmArgsT<Real> g{};
+      g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
+      g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
+      g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
+      g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+      if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g))) return rc;
+    }
+    if (i + 1 >= Wp) break;
+    if ((rc = gemm_sub_auto(h, sp, upd_args(c, c + 1, 0, 1)))) return rc;
+    const int rest = Wp - i - 2;
+    if (rest > 0) {
+      GemmArgsT<Real> gu = upd_args(c, c + 1, 1, 1 + rest);
+      gu.r0 *= 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2;
+      rc = diag(c + 1, &gu);
+    } else {
+      rc = diag(c + 1, nullptr);
+    }
+    if (rc) return rc;
+  }
+  return SIGP_OK;
+}
+
+template <typename Real>
+int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
   const int T = (int)(n_pad / NB), R = T + 1;
   if (Wp == 1) {
     const int c = J0;
@@ -777,7 +841,7 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStrea
     return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   }
   const int hw = Wp / 2;
-  int rc = dist_panel<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, hw);
+  int rc = dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, hw);
   if (rc) return rc;
   {   // columns of the right half -= (left half)(left half)^T, rows from the right half's diagonal block down
     const long o = (long)(J0 + hw) * NB;
@@ -788,7 +852,7 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStrea
     g.batch = 1; g.K = hw * NB; g.r0 = 0; g.r1 = R - (J0 + hw); g.c0 = 0; g.c1 = Wp - hw; g.lower = 1;
     if ((rc = gemm_sub_auto(h, sp, g))) return rc;
   }
-  return dist_panel<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0 + hw, Wp - hw);
+  return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0 + hw, Wp - hw);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
