@@ -137,6 +137,7 @@ struct sigp_handle {
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
+  int opt_wide_tiles = 0;    // trailing updates on 128 x 256 workgroup tiles (syrk_wide_kernel): bit 0 fp64, bit 1 fp32
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
@@ -394,6 +395,16 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1)) * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
+    // 128 x 256 workgroup tiles (syrk_wide_kernel): lower updates over an even number of column blocks, plain walk
+    const int wide = sizeof(T) == 4 ? (h->opt_wide_tiles & 2) : (h->opt_wide_tiles & 1);
+    if (wide && g.lower && g.patch == 0 && g.ktri == 0 && ((g.c1 - g.c0) & 1) == 0 && !h->persist_now && h->opt_xcd_chunks == 0 &&
+        nt >= 4 * h->opt_small_tiles) {
+      static AttrOnce wattr;
+      HIPCHK(h, wattr.set(h->device, (const void*)syrk_wide_kernel<T>, SYW_LDS_BYTES));
+      hipLaunchKernelGGL(syrk_wide_kernel<T>, dim3((unsigned)syrk_wide_tiles(g.r0, g.r1, g.c0, g.c1), (unsigned)nb), dim3(512), SYW_LDS_BYTES, st, g);
+      HIPCHK(h, hipGetLastError());
+      return SIGP_OK;
+    }
     if (h->opt_c_dma) g.dbg |= 128;
     return launch_syrk128_t<T, false>(h, st, g, true);   // tile-walk options (xcd_chunks, update_wgs when persist_now) apply here
   }
@@ -1339,6 +1350,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "wide_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_wide_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
