@@ -259,7 +259,8 @@ int sigp_profile_reset(sigp_handle* h);
  *   bit 1: top blocks of strip-solved panels, are factored column by column with the other columns' update riding in the diagonal-block
  *   launch; 0 = binary recursion), chain_rows [80] (bit 0 applies while rows-below x members <= this), first_on_panel [1] (the update of
  *   the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always), wide_tiles [0] (trailing updates on
- *   128 x 256 workgroup tiles, syrk_wide_kernel: bit 0 fp64, bit 1 fp32; bit-identical, measured slower / neutral)
+ *   128 x 256 workgroup tiles, syrk_wide_kernel: bit 0 fp64, bit 1 fp32; bit-identical, measured slower / neutral), n64_tiles [0]
+ *   (128 x 64 tiles, three workgroups per CU, syrk_n64_kernel; same bits, same verdict)
  *   pan_priority, diag_prio, patch, reserve_cus, host_timing   measurement switches; c_dma, syrk_v2: libsigp_debug.so only */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
 

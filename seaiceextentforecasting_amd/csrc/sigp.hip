@@ -137,6 +137,7 @@ struct sigp_handle {
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
+  int opt_n64_tiles = 0;     // trailing updates on 128 x 64 workgroup tiles, 3 workgroups per CU (syrk_n64_kernel): bit 0 fp64, bit 1 fp32
   int opt_wide_tiles = 0;    // trailing updates on 128 x 256 workgroup tiles (syrk_wide_kernel): bit 0 fp64, bit 1 fp32
   int opt_syrk_v2 = 1;       // trailing update on syrk128_kernel (LDS-DMA, swizzled) instead of the generic kernel
   int opt_patch = 0;         // tile walk of the lower updates: 0 column-major, P = PxP patches per XCD
@@ -402,6 +403,16 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
       static AttrOnce wattr;
       HIPCHK(h, wattr.set(h->device, (const void*)syrk_wide_kernel<T>, SYW_LDS_BYTES));
       hipLaunchKernelGGL(syrk_wide_kernel<T>, dim3((unsigned)syrk_wide_tiles(g.r0, g.r1, g.c0, g.c1), (unsigned)nb), dim3(512), SYW_LDS_BYTES, st, g);
+      HIPCHK(h, hipGetLastError());
+      return SIGP_OK;
+    }
+    // 128 x 64 workgroup tiles, three workgroups per CU (syrk_n64_kernel)
+    const int n64 = sizeof(T) == 4 ? (h->opt_n64_tiles & 2) : (h->opt_n64_tiles & 1);
+    if (n64 && g.patch == 0 && g.ktri == 0 && !h->persist_now && h->opt_xcd_chunks == 0) {
+      static AttrOnce nattr;
+      HIPCHK(h, nattr.set(h->device, (const void*)syrk_n64_kernel<T>, SYN_LDS_BYTES));
+      const int ntl = gemm_grid_size(g.r0, g.r1, g.c0, g.c1, g.lower, 0);
+      hipLaunchKernelGGL(syrk_n64_kernel<T>, dim3((unsigned)(2 * ntl), (unsigned)nb), dim3(256), SYN_LDS_BYTES, st, g);
       HIPCHK(h, hipGetLastError());
       return SIGP_OK;
     }
@@ -1350,6 +1361,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "patch")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_patch = (int)value; return SIGP_OK; }
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "n64_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_n64_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "wide_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_wide_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }

@@ -356,6 +356,112 @@ __global__ __launch_bounds__(512) void syrk_wide_kernel(GemmArgsT<T> g) {
       for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = -acc[i][j][r];
 }
 
+// ---- 128 x 64 workgroup tile (4 waves of 64 x 32), three workgroups per CU ---------------------------------------------------
+// The opposite of the wide tile: half the tile's columns, so a workgroup needs 48 KiB of LDS and ~130 VGPRs per wave and THREE of
+// them fit on a CU.  What the update kernel loses cycles to is not its operand stream but the moments when every resident
+// workgroup of a CU is outside its K loop (C-tile load / store under memory load): a third workgroup covers more of them.  Costs
+// 50 % more global -> LDS bytes and fragment reads per flop.  Same MFMA sequence per 16x16 accumulator and k order: bit-identical.
+constexpr int SYN_LDS_BYTES = 2 * (SY_T + SY_T / 2) * SY_SLICE_BYTES;   // 2 buffers x (128 A rows + 64 B rows) x 128 B = 48 KiB
+template <typename T>
+__global__ __launch_bounds__(256, 3) void syrk_n64_kernel(GemmArgsT<T> g) {
+  typedef Num<T> N_;
+  typedef typename N_::acc_t acc_t;
+  typedef typename N_::v16_t v16_t;
+  constexpr int KTe = N_::KT, NE = N_::NE;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* As = (T*)smem_raw;                 // [2][128][KT]
+  T* Bs = As + 2 * SY_T * KTe;          // [2][64][KT]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lq = lane >> 4;
+  int bi, bj;
+  if (!gemm_tile_coords(g, (int)(blockIdx.x >> 1), bi, bj)) return;      // two workgroups per 128 x 128 tile: its column halves
+  const int half = blockIdx.x & 1;
+  const long bz = blockIdx.y;
+  const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
+  const T* Bg = g.B + bz * g.sB + ((long)bj * SY_T + half * 64) * g.ldb;
+  T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + half * 64 + wn * 32;
+  const int K = g.K;
+
+  acc_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = -Cw[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr];
+
+  const int drow_ = wave * 8 + (lane >> 3);                  // 32 rows per round of the 4 waves
+  const int dks = ((lane & 7) ^ ((drow_ >> 1) & 7)) * NE;
+  const T* Asrc = Ag + (long)drow_ * g.lda + dks;
+  const T* Bsrc = Bg + (long)drow_ * g.ldb + dks;
+  const long a32 = 32 * g.lda, b32 = 32 * g.ldb;
+#define SYN_ISSUE(k0, buf)                                                                                     \
+  {                                                                                                            \
+    _Pragma("unroll") for (int p = 0; p < 4; ++p)                                                              \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Asrc + p * a32 + (k0)),                                     \
+                                       (lds_ptr_t)(As + ((buf) * SY_T + p * 32 + wave * 8) * KTe), 16, 0, 0);  \
+    _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                              \
+      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bsrc + p * b32 + (k0)),                                     \
+                                       (lds_ptr_t)(Bs + ((buf) * 64 + p * 32 + wave * 8) * KTe), 16, 0, 0);    \
+  }
+  const int x = (lr >> 1) & 7;
+  const int fo0 = ((lq ^ x) & 7) * NE, fo1 = (((4 + lq) ^ x) & 7) * NE;
+  const int arow0 = (wm * 64 + lr) * KTe, brow0 = (wn * 32 + lr) * KTe;
+  const int nst = K / KTe;
+  v16_t a0[4], b0[2], a1[4], b1[2];
+  SYN_ISSUE(0, 0);
+  __syncthreads();
+  if (nst > 1) SYN_ISSUE(KTe, 1);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) b0[j] = *(const v16_t*)(Bs + brow0 + j * 16 * KTe + fo0);
+  for (int s = 0; s < nst; ++s) {
+    const int buf = s & 1;
+    const T* Ab = As + buf * SY_T * KTe + arow0;
+    const T* Bb = Bs + buf * 64 * KTe + brow0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < nst) SYN_ISSUE((s + 2) * KTe, buf);
+    if (s + 1 < nst) {
+      const T* An = As + (buf ^ 1) * SY_T * KTe + arow0;
+      const T* Bn = Bs + (buf ^ 1) * 64 * KTe + brow0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(An + i * 16 * KTe + fo0);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b0[j] = *(const v16_t*)(Bn + j * 16 * KTe + fo0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < NE; ++e)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#undef SYN_ISSUE
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = -acc[i][j][r];
+}
+
 // Panel solve by row strips (panel_mode 1).  The top Wp x Wp block of a panel is already factored and
 //   Mt = [ inv(L_00)                                   ]      (block row j: -inv(L_jj) L_jk for k < j, inv(L_jj) at k = j)
 //        [ -inv(L_11) L_10   inv(L_11)                 ]

@@ -294,7 +294,7 @@ def test_mlii_gradient_at_multi_block_sizes(S, kind, n, d):
     assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= max(TOL_PRED, 1e-6 * float(np.exp(th[1])))
 
 
-@pytest.mark.parametrize("opt,val", [("xcd_chunks", 8), ("xcd_chunks", 5), ("update_wgs", 1), ("update_wgs", 37), ("wide_tiles", 1)])
+@pytest.mark.parametrize("opt,val", [("xcd_chunks", 8), ("xcd_chunks", 5), ("update_wgs", 1), ("update_wgs", 37), ("wide_tiles", 1), ("n64_tiles", 1)])
 def test_tile_walk_options_only_move_tiles(S, opt, val):
     """The XCD-chunked walk and the persistent-grid walk of the trailing update place tiles on different workgroups and
     nothing else: factor and results bit-identical to the default walk, single fit (two streams) and lockstep batch."""
