@@ -1008,270 +1008,7 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* din
   return SIGP_OK;
 }
 
-// ---- fp32 engine: fp32 kernel matrix + Cholesky, fp64 iterative refinement of alpha~ and w_j -----------------
-// (BASELINE configs[4]; no reference counterpart -- the reference is fp64 NumPy.  Same outputs as the fp64 path:
-//  sigma_f, nlML, mean, var of north/June1st.py:267-277, 246.)
-constexpr int REFINE_CHUNKS = 64;
-int f32_reserve(sigp_handle* h, long n_pad, int G = 1) {
-  if (h->cap_f_npad >= n_pad && h->cap_f_G >= G) return SIGP_OK;
-  n_pad = std::max(n_pad, h->cap_f_npad); G = std::max(G, h->cap_f_G);
-  HIPCHK(h, hipDeviceSynchronize());
-  for (float** p : {&h->fmat, &h->fdinv, &h->fZ, &h->fU, &h->fV, &h->fXw}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-  for (double** p : {&h->xq, &h->rq, &h->rpart, &h->fpart}) if (*p) { HIPCHK(h, hipFree(*p)); *p = nullptr; }
-  h->cap_f_npad = 0; h->cap_f_G = 0;
-  // G lockstep members of the factor (batch path); the solve / refinement workspaces below serve one member at a time
-  HIPCHK(h, hipMalloc((void**)&h->fmat, (size_t)G * (n_pad + RIDE) * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fdinv, (size_t)G * (n_pad / NB) * NB * NB * sizeof(float)));
-  HIPCHK(h, hipMemset(h->fdinv, 0, (size_t)G * (n_pad / NB) * NB * NB * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fZ, (size_t)RIDE * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fU, (size_t)n_pad * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fV, (size_t)n_pad * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->fXw, (size_t)TS_RHS * n_pad * sizeof(float)));
-  HIPCHK(h, hipMalloc((void**)&h->xq, (size_t)4 * n_pad * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->rq, (size_t)4 * n_pad * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->rpart, (size_t)REFINE_CHUNKS * 4 * n_pad * sizeof(double)));
-  HIPCHK(h, hipMalloc((void**)&h->fpart, (size_t)(n_pad / 256 + 1) * 8 * sizeof(double)));
-  HIPCHK(h, hipDeviceSynchronize());
-  h->cap_f_npad = n_pad; h->cap_f_G = G;
-  return SIGP_OK;
-}
-
-#define SIGP_DREG_DISPATCH(d, CALL)            \
-  do {                                         \
-    if ((d) <= 8) { CALL(8); }                 \
-    else if ((d) <= 16) { CALL(16); }          \
-    else if ((d) <= 32) { CALL(32); }          \
-    else { CALL(64); }                         \
-  } while (0)
-
-// one fp32 fit on slot 0's streams from device-resident X [n_pad][dp], y [n_pad], Xs [128][dp] (m <= 3 ride points)
-// fp32 engine in three steps so that the multi-GPU driver can put its own panel loop in the middle:
-//   f32_build  fp32 kernel matrix + ride rows into fmat;   factor (potrf_core<float> or the sigp_dist_* panel loop);
-//   f32_finish reductions, x0, fp64 iterative refinement, results
-int f32_build(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
-              long dp, long n_pad, long m) {
-  if (m > 3) return fail(h, SIGP_BAD_ARG, "fp32 engine: at most 3 ride-along test points (refinement solves 1+m systems)");
-  if (d > 64) return fail(h, SIGP_BAD_ARG, "fp32 engine: d <= 64 required");
-  Slot& s = h->slots[0];
-  hipStream_t st = s.s_upd;
-  const long ld = n_pad;
-  int rc;
-  if ((rc = f32_reserve(h, n_pad))) return rc;
-  if ((rc = slot_reserve(h, s, NB, 1))) return rc;     // res / info / kps buffers only
-  const KParams kp = make_kparams(kernel_id, ell, sn, 0);
-  s.kps_host[0] = kp;
-  if ((rc = upload_kparams(h, s, 1))) return rc;
-  {
-    ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * n / 2 * (3.0 * d + 20), 8.0 * n * d + 2.0 * n * (n + 1));
-    dim3 grid((unsigned)kbuild_tiles(n_pad), 1, 1);
-    hipLaunchKernelGGL(kbuild_kernel<float>, grid, dim3(256), 0, st, X, 0L, (int)dp, (int)d, (int)n, h->fmat, 0L, ld, s.kps, 0);
-    HIPCHK(h, hipGetLastError());
-    dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, 1);
-    hipLaunchKernelGGL(ride_build_kernel<float>, g2, dim3(256), 0, st, X, 0L, Xs, 0L, y, 0L, (int)dp, (int)d, (int)n, (int)n_pad, (int)m, 1,
-                       h->fmat + n_pad * ld, 0L, ld, s.kps, 1);
-    HIPCHK(h, hipGetLastError());
-  }
-  return SIGP_OK;
-}
-
-// ---- block triangular solves of the fp32 refinement (kernels_misc.hpp: rowdot / coldot) ------------------------------
-// forward:  X = Z L^-T  (rows = right-hand sides; Z is consumed), backward:  Z = X L^-1 (X is consumed).  Right-looking over
-// the 2048-column big blocks: product with the explicit inverse of the diagonal block, then one update of everything left.
-int f32_block_forward(sigp_handle* h, hipStream_t st, long n_pad, int nrhs, float* Zw, float* Xout) {
-  const long ld = n_pad;
-  for (long c0 = 0; c0 < n_pad; c0 += TS_BS) {
-    const int kb = (int)std::min<long>(TS_BS, n_pad - c0);
-    const long rem = n_pad - (c0 + kb);
-    ProfScope ps(h, st, SIGP_KC_TRSM, 2.0 * nrhs * ((double)kb * kb / 2 + (double)rem * kb), 4.0 * ((double)kb * kb / 2 + (double)rem * kb));
-    hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((kb + 3) / 4)), dim3(256), 0, st, (const float*)(h->fV + c0 * (ld + 1)), ld, kb, kb, 1,
-                       (const float*)(Zw + c0), ld, Xout + c0, ld, nrhs, 0);
-    if (rem > 0)
-      hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((rem + 3) / 4)), dim3(256), 0, st, (const float*)(h->fmat + (c0 + kb) * ld + c0), ld, (int)rem, kb, 0,
-                         (const float*)(Xout + c0), ld, Zw + c0 + kb, ld, nrhs, 1);
-    HIPCHK(h, hipGetLastError());
-  }
-  return SIGP_OK;
-}
-
-int f32_block_backward(sigp_handle* h, hipStream_t st, long n_pad, int nrhs, float* Xw, float* Zout) {
-  const long ld = n_pad;
-  const long nbig = (n_pad + TS_BS - 1) / TS_BS;
-  for (long b = nbig - 1; b >= 0; --b) {
-    const long c0 = b * TS_BS;
-    const int kb = (int)std::min<long>(TS_BS, n_pad - c0);
-    ProfScope ps(h, st, SIGP_KC_TRSM, 2.0 * nrhs * ((double)kb * kb / 2 + (double)c0 * kb), 4.0 * ((double)kb * kb / 2 + (double)c0 * kb));
-    hipLaunchKernelGGL(rowdot_kernel<float>, dim3((unsigned)((kb + 3) / 4)), dim3(256), 0, st, (const float*)(h->fU + c0 * (ld + 1)), ld, kb, kb, 2,
-                       (const float*)(Xw + c0), ld, Zout + c0, ld, nrhs, 0);
-    if (c0 > 0)
-      hipLaunchKernelGGL(coldot_kernel<float>, dim3((unsigned)(c0 / 64)), dim3(256), 0, st, (const float*)(h->fmat + c0 * ld), ld, (int)c0, kb,
-                         (const float*)(Zout + c0), ld, Xw, ld, nrhs);
-    HIPCHK(h, hipGetLastError());
-  }
-  return SIGP_OK;
-}
-
-// `member`: which lockstep member's reductions / info to use (h->fmat / h->fdinv already point at that member's factor)
-int f32_finish(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
-               long dp, long n_pad, long m, double* out, double* mean, double* var, int member = 0) {
-  Slot& s = h->slots[0];
-  hipStream_t st = s.s_upd;
-  const long ld = n_pad;
-  const int nrhs = (int)(1 + m);
-  const KParams kp = make_kparams(kernel_id, ell, sn, 0);
-  int rc;
-  {
-    const float* Z = h->fmat + n_pad * ld;
-    hipLaunchKernelGGL(epilogue_kernel<float>, dim3((unsigned)(m + 2), 1), dim3(256), 0, st, Z, ld, Z, (const float*)h->fmat, ld, (int)n,
-                       (int)n_pad, (int)(m + 1), s.res + 512 * member, 0L, 0L, 0L);
-    HIPCHK(h, hipGetLastError());
-  }
-  HIPCHK(h, hipMemcpyAsync(s.res_host + 512 * member, s.res + 512 * member, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(s.info_host + member, s.info + member, sizeof(int), hipMemcpyDeviceToHost, st));
-  // inverse-transposes of the factor's 2048-column diagonal blocks (fU) and their transposes (fV; it is the scratch of the
-  // inversion first), for the block triangular solves below
-  {
-    const int T = (int)(n_pad / NB);
-    ProfScope ps(h, st, SIGP_KC_MLII, (double)n_pad * TS_BS * TS_BS / 3, 0.0);
-    if ((rc = trtri_levels<float>(h, st, h->fmat, h->fdinv, h->fU, h->fV, ld, T, TS_BS / NB))) return rc;
-    const int nbig = (int)((n_pad + TS_BS - 1) / TS_BS);
-    hipLaunchKernelGGL(transpose_diag_blocks_kernel<float>, dim3(TS_BS / 32, TS_BS / 32, (unsigned)nbig), dim3(256), 0, st, (const float*)h->fU, h->fV, ld, (int)n_pad, TS_BS);
-    HIPCHK(h, hipGetLastError());
-  }
-  // x0 = L^-T (L^-1 b): the ride rows already hold L^-1 [y k*]; one backward block solve finishes them
-  HIPCHK(h, hipMemcpyAsync(h->fXw, h->fmat + n_pad * ld, (size_t)nrhs * n_pad * sizeof(float), hipMemcpyDeviceToDevice, st));
-  if ((rc = f32_block_backward(h, st, n_pad, nrhs, h->fXw, h->fZ))) return rc;
-  {
-    const long tot = (long)nrhs * n_pad;
-    hipLaunchKernelGGL((convert_rows_kernel<float, double>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld,
-                       nrhs, (int)n_pad, (int)n);
-    HIPCHK(h, hipGetLastError());
-  }
-  const unsigned nblk = (unsigned)((n + 255) / 256);
-  // the columns of a residual in chunks, so that the launch fills the chip (~8 workgroups per CU): chunk length a multiple of 64
-  const int want = (int)std::min<long>(REFINE_CHUNKS, std::max<long>(1, 2048 / nblk));
-  const int jlen = (int)(((n + want - 1) / want + 63) / 64 * 64);
-  const unsigned nchunk = (unsigned)((n + jlen - 1) / jlen);
-  double ymax_dev = -1.0;
-  for (int it = 0; it <= h->opt_refine_iters; ++it) {
-    // r = b - K~ x in fp64, covariance recomputed on the fly
-#define CALL_RES(D) hipLaunchKernelGGL(krefine_residual_kernel<D>, dim3(nblk, nchunk), dim3(256), 0, st, X, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->rpart, ld, jlen, kp)
-    SIGP_DREG_DISPATCH(d, CALL_RES);
-#undef CALL_RES
-    HIPCHK(h, hipGetLastError());
-#define CALL_FIN(D) hipLaunchKernelGGL(krefine_finish_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->rpart, ld, (int)nchunk, h->rq, ld, kp)
-    SIGP_DREG_DISPATCH(d, CALL_FIN);
-#undef CALL_FIN
-    HIPCHK(h, hipGetLastError());
-    if (it == h->opt_refine_iters) break;    // the last pass only measures the residual
-    if (h->opt_refine_tol_e > 0 && it > 0) {
-      // converged already?  (every right-hand side: y against max|y|, the unit-variance cross-covariances against 1)  Then this
-      // residual is the final measurement: one residual + one solve pair saved on every well-conditioned fit
-      std::vector<double> rr((size_t)nrhs * n);
-      for (int r = 0; r < nrhs; ++r) HIPCHK(h, hipMemcpyAsync(rr.data() + (size_t)r * n, h->rq + (size_t)r * ld, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-      if (ymax_dev < 0) {
-        std::vector<double> yh0((size_t)n);
-        HIPCHK(h, hipMemcpyAsync(yh0.data(), y, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(h, hipStreamSynchronize(st));
-        ymax_dev = 0; for (long i = 0; i < n; ++i) ymax_dev = std::max(ymax_dev, std::fabs(yh0[i]));
-      } else {
-        HIPCHK(h, hipStreamSynchronize(st));
-      }
-      double worst = 0;
-      for (int r = 0; r < nrhs; ++r) {
-        double mx = 0; for (long i = 0; i < n; ++i) mx = std::max(mx, std::fabs(rr[(size_t)r * n + i]));
-        worst = std::max(worst, r == 0 ? (ymax_dev > 0 ? mx / ymax_dev : 0.0) : mx);
-      }
-      if (worst <= std::pow(10.0, -(double)h->opt_refine_tol_e)) break;
-    }
-    const long tot = (long)nrhs * n_pad;
-    hipLaunchKernelGGL((convert_rows_kernel<double, float>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const double*)h->rq, ld, h->fZ, ld,
-                       nrhs, (int)n_pad, (int)n);
-    HIPCHK(h, hipGetLastError());
-    if ((rc = f32_block_forward(h, st, n_pad, nrhs, h->fZ, h->fXw))) return rc;
-    if ((rc = f32_block_backward(h, st, n_pad, nrhs, h->fXw, h->fZ))) return rc;
-    hipLaunchKernelGGL(accumulate_rows_kernel<float>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)h->fZ, ld, h->xq, ld, nrhs,
-                       (int)n_pad);
-    HIPCHK(h, hipGetLastError());
-  }
-#define CALL_DOT(D) hipLaunchKernelGGL(krefine_dots_kernel<D>, dim3(nblk), dim3(256), 0, st, X, Xs, y, (int)dp, (int)n, nrhs, (const double*)h->xq, ld, h->fpart, kp)
-  SIGP_DREG_DISPATCH(d, CALL_DOT);
-#undef CALL_DOT
-  HIPCHK(h, hipGetLastError());
-  std::vector<double> part((size_t)nblk * 8), r0((size_t)n), yh((size_t)n);
-  HIPCHK(h, hipMemcpyAsync(part.data(), h->fpart, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(r0.data(), h->rq, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(yh.data(), y, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  const int info = s.info_host[member];
-  const double inf = std::numeric_limits<double>::infinity();
-  if (info != 0) {
-    out[0] = inf; out[1] = inf; out[2] = (double)info; out[3] = inf;
-    for (long j = 0; j < m; ++j) { if (mean) mean[j] = std::nan(""); if (var) var[j] = std::nan(""); }
-    return SIGP_OK;
-  }
-  double dots0[4] = {0, 0, 0, 0}, dots1[4] = {0, 0, 0, 0};
-  for (unsigned b = 0; b < nblk; ++b)
-    for (int r = 0; r < nrhs; ++r) { dots0[r] += part[(size_t)b * 8 + r]; dots1[r] += part[(size_t)b * 8 + 4 + r]; }
-  double rmax = 0, ymax = 0;
-  for (long i = 0; i < n; ++i) { rmax = std::max(rmax, std::fabs(r0[i])); ymax = std::max(ymax, std::fabs(yh[i])); }
-  h->refine_resid = ymax > 0 ? rmax / ymax : 0.0;
-  const double sf = dots0[0] / (double)n;                                   // y^T alpha~ / n
-  out[0] = sf;
-  out[1] = 0.5 * n + s.res_host[512 * member + 256] + 0.5 * n * std::log(sf) + 0.5 * n * std::log(2.0 * M_PI);   // log-det from the fp32 factor
-  out[2] = 0.0; out[3] = sf * sn;
-  for (long j = 0; j < m; ++j) {
-    if (mean) mean[j] = dots0[1 + j];                                       // k*^T alpha~
-    if (var) var[j] = sf * (1.0 + sn - dots1[1 + j]);                       // k** + sn~ - k*^T K~^-1 k*
-  }
-  return SIGP_OK;
-}
-
-int f32_fit(sigp_handle* h, int kernel_id, double ell, double sn, const double* X, const double* y, const double* Xs, long n, long d,
-            long dp, long n_pad, long m, double* out, double* mean, double* var) {
-  int rc = f32_build(h, kernel_id, ell, sn, X, y, Xs, n, d, dp, n_pad, m);
-  if (rc) return rc;
-  if ((rc = potrf_core<float>(h, h->slots[0], h->fmat, 0, h->fdinv, 0, 1, n_pad))) return rc;
-  return f32_finish(h, kernel_id, ell, sn, X, y, Xs, n, d, dp, n_pad, m, out, mean, var);
-}
-
-// nb fp32 fits of equal order in lockstep (batch path): one covariance build and one blocked Cholesky over all members
-// (grid.y / grid.z = member, as the fp64 lockstep batches), then the solves + fp64 refinement member by member (they are
-// HBM-bound streams of one factor each and share the workspaces).  kps_host[b] holds member b's hyper-parameters / data set.
-int f32_fit_lockstep(sigp_handle* h, int nb, int kernel_id, const double* ell, const double* sn, const long* ds, const double* bX, const double* by,
-                     const double* bXs, long n, long d, long dp, long n_pad, long m, double* out, double* mean, double* var) {
-  if (m > 3) return fail(h, SIGP_BAD_ARG, "fp32 engine: at most 3 ride-along test points (refinement solves 1+m systems)");
-  if (d > 64) return fail(h, SIGP_BAD_ARG, "fp32 engine: d <= 64 required");
-  Slot& s = h->slots[0];
-  hipStream_t st = s.s_upd;
-  const long ld = n_pad, fStride = (n_pad + RIDE) * n_pad, dStride = (n_pad / NB) * NB * NB;
-  int rc;
-  if ((rc = f32_reserve(h, n_pad, nb))) return rc;
-  if ((rc = slot_reserve(h, s, NB, nb))) return rc;     // res / info / kps buffers for nb members
-  for (int b = 0; b < nb; ++b) s.kps_host[b] = make_kparams(kernel_id, ell[b], sn[b], (int)ds[b]);
-  if ((rc = upload_kparams(h, s, nb))) return rc;
-  {
-    ProfScope ps(h, st, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 2.0 * n * (n + 1)));
-    hipLaunchKernelGGL(kbuild_kernel<float>, dim3((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb), dim3(256), 0, st, bX, n_pad * dp, (int)dp, (int)d, (int)n, h->fmat,
-                       fStride, ld, s.kps, 0);
-    hipLaunchKernelGGL(ride_build_kernel<float>, dim3((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb), dim3(256), 0, st, bX, n_pad * dp, bXs, (long)RIDE * dp, by, n_pad,
-                       (int)dp, (int)d, (int)n, (int)n_pad, (int)m, 1, h->fmat + n_pad * ld, fStride, ld, s.kps, 1);
-    HIPCHK(h, hipGetLastError());
-  }
-  if ((rc = potrf_core<float>(h, s, h->fmat, fStride, h->fdinv, dStride, nb, n_pad))) return rc;
-  float* const fm0 = h->fmat; float* const fd0 = h->fdinv;
-  for (int b = 0; b < nb && !rc; ++b) {
-    h->fmat = fm0 + b * fStride; h->fdinv = fd0 + b * dStride;        // view of member b for the solve / refinement code
-    rc = f32_finish(h, kernel_id, ell[b], sn[b], bX + ds[b] * n_pad * dp, by + ds[b] * n_pad, bXs + ds[b] * (long)RIDE * dp, n, d, dp, n_pad, m, out + 4 * b,
-                    mean ? mean + b * m : nullptr, var ? var + b * m : nullptr, b);
-  }
-  h->fmat = fm0; h->fdinv = fd0;
-  return rc;
-}
-
-int sync_slot(sigp_handle* h, Slot& s) {
-  HIPCHK(h, hipStreamSynchronize(s.s_upd));
-  return SIGP_OK;
-}
+#include "sigp_f32.inc"   // fp32 engine: build, factor, block solves, fp64 refinement
 
 }  // namespace
 
@@ -2101,522 +1838,9 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   return SIGP_OK;
 }
 
-// ---- the reference's own kernel at the reference's own size: one workgroup per fit (smallgp.hpp) ---------------------
-int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int64_t* N, const int64_t* m, const int32_t* lam_mode,
-                      const double* A_pool, const int64_t* A_off, const double* y_pool, const int64_t* y_off, const double* lam_pool,
-                      const int64_t* lam_off) {
-  if (!h || nsets < 1 || !n || !N || !m || !lam_mode || !A_pool || !A_off || !y_pool || !y_off || !lam_pool || !lam_off)
-    return fail(h, SIGP_BAD_ARG, "small_upload: bad argument");
-  if (h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "small_upload: fp64 engine only");
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<SmallSet> sets((size_t)nsets);
-  long totA = 0, toty = 0, totl = 0;
-  int nmax = 0, mmax = 0;
-  for (int64_t i = 0; i < nsets; ++i) {
-    if (n[i] < 1 || n[i] > SM_NMAX) return fail(h, SIGP_BAD_ARG, "small_upload: data set %ld has n = %ld; this path takes 1 <= n <= %d (larger fits go through sigp_fit_predict)", (long)i, (long)n[i], SM_NMAX);
-    if (N[i] < 1 || m[i] < 0 || m[i] > SM_MMAX) return fail(h, SIGP_BAD_ARG, "small_upload: data set %ld: N >= 1 and 0 <= m <= %d required", (long)i, SM_MMAX);
-    if (lam_mode[i] != 0 && lam_mode[i] != 1) return fail(h, SIGP_BAD_ARG, "small_upload: lam_mode must be 0 (exp(l lam)) or 1 (weights)");
-    if (A_off[i] < 0 || y_off[i] < 0 || lam_off[i] < 0) return fail(h, SIGP_BAD_ARG, "small_upload: negative offset");
-    SmallSet& s = sets[(size_t)i];
-    s.a_off = A_off[i]; s.y_off = y_off[i]; s.lam_off = lam_off[i];
-    s.n = (int)n[i]; s.N = (int)N[i]; s.m = (int)m[i]; s.lam_mode = lam_mode[i];
-    totA = std::max<long>(totA, A_off[i] + (n[i] + m[i]) * N[i]);
-    toty = std::max<long>(toty, y_off[i] + n[i]);
-    totl = std::max<long>(totl, lam_off[i] + N[i]);
-    nmax = std::max(nmax, s.n); mmax = std::max(mmax, s.m);
-  }
-  // feature chunk: the largest of 32 / 16 / 8 whose LDS image fits beside the bordered matrix of the largest data set
-  constexpr long LDS_MAX = 160 * 1024 - 64;
-  int ch = 32;
-  while (ch > 8 && smallgp_lds_bytes(nmax, mmax, ch) > LDS_MAX) ch /= 2;
-  if (smallgp_lds_bytes(nmax, mmax, ch) > LDS_MAX) return fail(h, SIGP_BAD_ARG, "small_upload: n = %d with m = %d does not fit in LDS", nmax, mmax);
-  int rc;
-  if ((rc = ensure(h, &h->sm_A, &h->cap_sm_A, totA))) return rc;
-  if ((rc = ensure(h, &h->sm_y, &h->cap_sm_y, toty))) return rc;
-  if ((rc = ensure(h, &h->sm_lam, &h->cap_sm_lam, totl))) return rc;
-  if (h->sm_sets_dev) { HIPCHK(h, hipFree(h->sm_sets_dev)); h->sm_sets_dev = nullptr; }
-  HIPCHK(h, hipMalloc((void**)&h->sm_sets_dev, sets.size() * sizeof(SmallSet)));
-  HIPCHK(h, hipMemcpy(h->sm_sets_dev, sets.data(), sets.size() * sizeof(SmallSet), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->sm_A, A_pool, (size_t)totA * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->sm_y, y_pool, (size_t)toty * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHK(h, hipMemcpy(h->sm_lam, lam_pool, (size_t)totl * sizeof(double), hipMemcpyHostToDevice));
-  h->sm_sets.swap(sets);
-  h->sm_ch = ch; h->sm_mmax = mmax; h->sm_nmax = nmax; h->sm_lds = smallgp_lds_bytes(nmax, mmax, ch);
-  return SIGP_OK;
-}
+#include "sigp_callers.inc"   // sigp_small_*, sigp_corr_tau, sigp_area_sums, sigp_detrend
 
-int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde, double* out,
-                   double* mean, double* var, int64_t mstride) {
-  if (!h || h->sm_sets.empty()) return fail(h, SIGP_BAD_ARG, "small_run: call sigp_small_upload first");
-  if (nprob < 1 || !set_index || !ell || !sn_tilde || !out) return fail(h, SIGP_BAD_ARG, "small_run: bad argument");
-  if (h->sm_mmax > 0 && (!mean || !var || mstride < h->sm_mmax)) return fail(h, SIGP_BAD_ARG, "small_run: mean / var [nprob][mstride >= %d] required", h->sm_mmax);
-  HIPCHK(h, hipSetDevice(h->device));
-  std::vector<SmallProb> probs((size_t)nprob);
-  for (int64_t i = 0; i < nprob; ++i) {
-    if (set_index[i] < 0 || set_index[i] >= (int64_t)h->sm_sets.size()) return fail(h, SIGP_BAD_ARG, "small_run: fit %ld names data set %ld of %zu", (long)i, (long)set_index[i], h->sm_sets.size());
-    if (!(sn_tilde[i] >= 0) || !std::isfinite(ell[i])) return fail(h, SIGP_BAD_ARG, "small_run: finite ell and sn_tilde >= 0 required");
-    probs[(size_t)i] = SmallProb{(int)set_index[i], 0, ell[i], sn_tilde[i]};
-  }
-  const long ms = std::max<int64_t>(mstride, 1);
-  const long per = 4 + 2 * ms;
-  if (h->cap_sm_probs < nprob) {
-    if (h->sm_probs) HIPCHK(h, hipFree(h->sm_probs));
-    h->sm_probs = nullptr; h->cap_sm_probs = 0;
-    HIPCHK(h, hipMalloc((void**)&h->sm_probs, (size_t)nprob * sizeof(SmallProb)));
-    h->cap_sm_probs = nprob;
-  }
-  int rc;
-  if ((rc = ensure(h, &h->sm_out, &h->cap_sm_out, nprob * per))) return rc;
-  hipStream_t st = h->slots[0].s_upd;
-  HIPCHK(h, hipMemcpyAsync(h->sm_probs, probs.data(), probs.size() * sizeof(SmallProb), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemsetAsync(h->sm_out, 0xff, (size_t)(nprob * per) * sizeof(double), st));   // NaN wherever a set has fewer test points than mstride
-  static AttrOnce attr64, attr256;
-  HIPCHK(h, attr64.set(h->device, (const void*)smallgp_kernel<64>, 160 * 1024 - 64));
-  HIPCHK(h, attr256.set(h->device, (const void*)smallgp_kernel<256>, 160 * 1024 - 64));
-  double* d_out = h->sm_out;
-  double* d_mean = h->sm_out + nprob * 4;
-  double* d_var = d_mean + nprob * ms;
-  {
-    double fl = 0;
-    for (const auto& pb : probs) { const SmallSet& s = h->sm_sets[(size_t)pb.set]; fl += (double)s.n * s.n * s.N + (double)s.n * s.n * s.n / 3 + 2.0 * s.n * s.n * (1 + s.m); }
-    ProfScope ps(h, st, SIGP_KC_SMALL, fl, 0.0);
-    // orders up to 64 (the reference's n <= 45): one wavefront per fit; larger: four
-    // measured on the reference-size grid (48 000 fits, n = 6 .. 45): four wavefronts per fit 1.02 ms, one wavefront per fit 1.71 ms
-    if (h->sm_nmax <= 64 && h->opt_small_nt64)
-      hipLaunchKernelGGL(smallgp_kernel<64>, dim3((unsigned)nprob), dim3(64), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
-                         h->sm_ch, d_out, d_mean, d_var, (int)ms);
-    else
-      hipLaunchKernelGGL(smallgp_kernel<256>, dim3((unsigned)nprob), dim3(256), (size_t)h->sm_lds, st, h->sm_sets_dev, h->sm_probs, h->sm_A, h->sm_y, h->sm_lam,
-                         h->sm_ch, d_out, d_mean, d_var, (int)ms);
-    HIPCHK(h, hipGetLastError());
-  }
-  HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)nprob * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (h->sm_mmax > 0) {
-    // device rows have pitch ms; the caller's have pitch mstride (== ms whenever mstride >= 1)
-    HIPCHK(h, hipMemcpyAsync(mean, d_mean, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(h, hipMemcpyAsync(var, d_var, (size_t)nprob * ms * sizeof(double), hipMemcpyDeviceToHost, st));
-  }
-  HIPCHK(h, hipStreamSynchronize(st));
-  return SIGP_OK;
-}
-
-// ---- ComplexNetworks tau(): cell-to-cell correlation matrix + thresholded mean (ComplexNetworks.py:31-47) ------------
-int sigp_corr_tau(sigp_handle* h, const double* series, int64_t N, int64_t T, int64_t lds, double r_crit, double* R, int64_t ldr,
-                  double* sum_out, double* count_out) {
-  if (!h || !series || N < 2 || T < 3 || lds < T || !sum_out || !count_out || (R && ldr < N)) return fail(h, SIGP_BAD_ARG, "corr_tau: bad argument");
-  if (N > 46000) return fail(h, SIGP_BAD_ARG, "corr_tau: more than 46000 cells not supported (tile index range)");
-  HIPCHK(h, hipSetDevice(h->device));
-  hipStream_t st = h->slots[0].s_upd;
-  const long n_pad = round_up(N, 64), k_pad = round_up(T, 16);
-  int rc;
-  // workspaces: raw series | Z | R | partial sums, carved out of the gradient buffers (n x n class)
-  if ((rc = ensure(h, &h->stage, &h->cap_stage, N * lds))) return rc;
-  if ((rc = ensure(h, &h->gD, &h->cap_gD, n_pad * k_pad))) return rc;
-  if ((rc = ensure(h, &h->gK, &h->cap_gK, n_pad * n_pad))) return rc;
-  if ((rc = ensure(h, &h->gPart, &h->cap_gPart, 2 * n_pad))) return rc;
-  HIPCHK(h, hipMemcpyAsync(h->stage, series, (size_t)((N - 1) * lds + T) * sizeof(double), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(corr_standardise_kernel, dim3((unsigned)((n_pad + 127) / 128)), dim3(128), 0, st, (const double*)h->stage, (long)lds, (int)N, (int)T, h->gD, (int)n_pad,
-                     (int)k_pad);
-  HIPCHK(h, hipGetLastError());
-  {
-    GemmArgs g{};                                         // R = Z Z^T, all 64x64 tiles (area_level reads the full symmetric matrix)
-    g.A = h->gD; g.lda = k_pad; g.B = h->gD; g.ldb = k_pad; g.C = h->gK; g.ldc = n_pad; g.K = (int)k_pad;
-    g.r0 = 0; g.r1 = (int)(n_pad / 64); g.c0 = 0; g.c1 = (int)(n_pad / 64); g.lower = 0;
-    ProfScope ps(h, st, SIGP_KC_KBUILD, 2.0 * N * N * T, 8.0 * N * N);
-    if ((rc = launch_gemm_cfg<64, 64, 2, 2, GEMM_SET, false>(h, st, g))) return rc;
-  }
-  hipLaunchKernelGGL(corr_threshold_kernel, dim3((unsigned)N), dim3(256), 0, st, h->gK, n_pad, (int)N, r_crit, h->gPart);
-  HIPCHK(h, hipGetLastError());
-  std::vector<double> part((size_t)2 * N);
-  HIPCHK(h, hipMemcpyAsync(part.data(), h->gPart, part.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-  if (R) HIPCHK(h, hipMemcpy2DAsync(R, (size_t)ldr * sizeof(double), h->gK, (size_t)n_pad * sizeof(double), (size_t)N * sizeof(double), (size_t)N, hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  double s = 0, c = 0;
-  for (int64_t i = 0; i < N; ++i) { s += part[2 * i]; c += part[2 * i + 1]; }
-  *sum_out = s; *count_out = c;
-  return SIGP_OK;
-}
-
-// ---- intra_links(): the per-area anomaly series that become the GP's features ----------------------------------------------
-int sigp_area_sums(sigp_handle* h, const double* data, int64_t P, int64_t T, const double* weight, const int32_t* label, int64_t A, double* out) {
-  if (!h || !data || !weight || !label || !out || P < 1 || T < 1 || A < 1) return fail(h, SIGP_BAD_ARG, "area_sums: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  hipStream_t st = h->slots[0].s_upd;
-  int rc;
-  const long lab_dbl = (P + 1) / 2;                                  // int32 labels, in doubles
-  if ((rc = ensure(h, &h->stage, &h->cap_stage, P * T + P + lab_dbl + A * T))) return rc;
-  double* d_data = h->stage; double* d_w = d_data + P * T; int* d_lab = (int*)(d_w + P); double* d_out = d_w + P + lab_dbl;
-  HIPCHK(h, hipMemcpyAsync(d_data, data, (size_t)(P * T) * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_w, weight, (size_t)P * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_lab, label, (size_t)P * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(area_sums_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)A), dim3(64), 0, st, (const double*)d_data, (const double*)d_w, (const int*)d_lab, (int)P,
-                     (int)T, (int)A, d_out);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(out, d_out, (size_t)(A * T) * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  return SIGP_OK;
-}
-
-// ---- detrend(): per-pixel least-squares line removal for every cut-off year in one launch --------------------------------
-int sigp_detrend(sigp_handle* h, const double* data, int64_t P, int64_t T, int64_t ncuts, const int64_t* cut_len, double* dt_out, double* trend_out) {
-  if (!h || !data || P < 1 || T < 2 || ncuts < 1 || !cut_len || !dt_out || !trend_out) return fail(h, SIGP_BAD_ARG, "detrend: bad argument");
-  std::vector<int> nc((size_t)ncuts);
-  std::vector<long> off((size_t)ncuts);
-  long tot = 0;
-  for (int64_t c = 0; c < ncuts; ++c) {
-    if (cut_len[c] < 2 || cut_len[c] > T) return fail(h, SIGP_BAD_ARG, "detrend: cut %ld uses %ld of %ld time steps", (long)c, (long)cut_len[c], (long)T);
-    nc[(size_t)c] = (int)cut_len[c]; off[(size_t)c] = tot; tot += P * cut_len[c];
-  }
-  HIPCHK(h, hipSetDevice(h->device));
-  hipStream_t st = h->slots[0].s_upd;
-  int rc;
-  const long hdr = round_up(ncuts * 2, 8);                       // cut lengths (int) + offsets (long), in doubles
-  if ((rc = ensure(h, &h->stage, &h->cap_stage, P * T + hdr + 8))) return rc;
-  if ((rc = ensure(h, &h->gD, &h->cap_gD, tot + ncuts * P * 2))) return rc;
-  double* d_data = h->stage;
-  long* d_off = (long*)(h->stage + P * T);
-  int* d_nc = (int*)(d_off + ncuts);
-  double* d_dt = h->gD;
-  double* d_tr = h->gD + tot;
-  HIPCHK(h, hipMemcpyAsync(d_data, data, (size_t)(P * T) * sizeof(double), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_off, off.data(), (size_t)ncuts * sizeof(long), hipMemcpyHostToDevice, st));
-  HIPCHK(h, hipMemcpyAsync(d_nc, nc.data(), (size_t)ncuts * sizeof(int), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(detrend_kernel, dim3((unsigned)((P + 127) / 128), (unsigned)ncuts), dim3(128), 0, st, (const double*)d_data, (int)P, (int)T, (const int*)d_nc,
-                     (const long*)d_off, (int)ncuts, d_dt, d_tr);
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(dt_out, d_dt, (size_t)tot * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipMemcpyAsync(trend_out, d_tr, (size_t)(ncuts * P * 2) * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  return SIGP_OK;
-}
-
-// ---- one large fit sharded over GPUs: panel-level entry points (host side: dist.DistributedGPR) ------------
-int64_t sigp_num_blocks(sigp_handle* h) { return h ? h->n_pad / NB : 0; }
-
-int sigp_dist_begin(sigp_handle* h) {
-  if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "dist_begin: build the kernel matrix first");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  static AttrOnce diag_attr64, diag_attr32;
-  if (h->dtype == SIGP_F64) {
-    HIPCHK(h, diag_attr64.set(h->device, (const void*)potrf_diag_kernel<double>, DIAG_LDS_BYTES));
-  } else {
-    HIPCHK(h, diag_attr32.set(h->device, (const void*)potrf_diag_kernel<float>, DIAG_LDS_BYTES));
-  }
-  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
-  return sync_slot(h, s);
-}
-
-static bool dist_args_ok(sigp_handle* h, int64_t J, int64_t W) {
-  return h && h->n > 0 && J >= 0 && W >= 1 && J + W <= h->n_pad / NB;
-}
-static size_t dist_esize(const sigp_handle* h) { return h->dtype == SIGP_F64 ? sizeof(double) : sizeof(float); }
-// the matrix / inverse-diagonal-block buffers the panel loop works on: the fp64 slot or the fp32 engine's
-static char* dist_mat(sigp_handle* h) { return h->dtype == SIGP_F64 ? (char*)h->slots[0].mat : (char*)h->fmat; }
-static char* dist_dinv(sigp_handle* h) { return h->dtype == SIGP_F64 ? (char*)h->slots[0].dinv : (char*)h->fdinv; }
-
-int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W) {
-  if (!dist_args_ok(h, J, W)) return -1;
-  const long rows = h->n_pad + RIDE - J * NB;          // rows J*128 .. end (ride block included)
-  return rows * W * NB + W * NB * NB;                  // panel + the W inverse diagonal blocks
-}
-
-int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info) {
-  if (!dist_args_ok(h, J, W)) return fail(h, SIGP_BAD_ARG, "dist_panel_factor: bad panel");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  // look-ahead mode: the panel is factored on the panel stream, after the update-stream work enqueued up to the
-  // last sigp_dist_mark (the update of this panel's columns), concurrently with the updates enqueued after the
-  // mark; later update-stream work waits for the factor
-  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
-  if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
-  int rc = h->dtype == SIGP_F64 ? dist_panel<double>(h, s, s.mat, h->n_pad, s.dinv, sp, h->n_pad, (int)J, (int)W)
-                                : dist_panel<float>(h, s, h->fmat, h->n_pad, h->fdinv, sp, h->n_pad, (int)J, (int)W);
-  if (rc) return rc;
-  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
-  if (h->opt_dist_async) {
-    HIPCHK(h, hipEventRecord(s.ev_pan, sp));
-    HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
-  }
-  HIPCHK(h, hipStreamSynchronize(sp));
-  if (info) *info = *s.info_host;
-  return SIGP_OK;
-}
-
-int sigp_dist_mark(sigp_handle* h) {
-  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_mark: no fit in progress");
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipEventRecord(h->slots[0].ev_la, h->slots[0].s_upd));
-  return SIGP_OK;
-}
-
-int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf) {
-  if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_pack: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;      // same stream as the factor that produced the panel
-  const size_t es = dist_esize(h);
-  const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
-  char* buf = (char*)dev_buf;
-  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * es, dist_mat(h) + (size_t)(J * NB * ld + J * NB) * es, (size_t)ld * es, (size_t)wcols * es, (size_t)rows,
-                             hipMemcpyDeviceToDevice, sp));
-  HIPCHK(h, hipMemcpyAsync(buf + (size_t)rows * wcols * es, dist_dinv(h) + (size_t)(J * NB * NB) * es, (size_t)W * NB * NB * es, hipMemcpyDeviceToDevice, sp));
-  HIPCHK(h, hipStreamSynchronize(sp));
-  return SIGP_OK;
-}
-
-int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf) {
-  if (!dist_args_ok(h, J, W) || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_panel_unpack: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  const size_t es = dist_esize(h);
-  const long ld = h->n_pad, rows = h->n_pad + RIDE - J * NB, wcols = W * NB;
-  const char* buf = (const char*)dev_buf;
-  // the copy runs on the panel stream: a rank never updates columns it does not own, so a received panel can land
-  // while the update stream is still busy with the previous panel's updates; the update stream waits for it
-  HIPCHK(h, hipMemcpy2DAsync(dist_mat(h) + (size_t)(J * NB * ld + J * NB) * es, (size_t)ld * es, buf, (size_t)wcols * es, (size_t)wcols * es, (size_t)rows,
-                             hipMemcpyDeviceToDevice, s.s_pan));
-  HIPCHK(h, hipMemcpyAsync(dist_dinv(h) + (size_t)(J * NB * NB) * es, buf + (size_t)rows * wcols * es, (size_t)W * NB * NB * es, hipMemcpyDeviceToDevice, s.s_pan));
-  HIPCHK(h, hipEventRecord(s.ev_pan, s.s_pan));
-  HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
-  if (h->opt_dist_async) return SIGP_OK;
-  HIPCHK(h, hipStreamSynchronize(s.s_pan));
-  return SIGP_OK;
-}
-
-int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1) {
-  if (!dist_args_ok(h, J, W) || c0 < 0 || c1 < c0 || J + W + c1 > h->n_pad / NB) return fail(h, SIGP_BAD_ARG, "dist_update: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  int rc = h->dtype == SIGP_F64 ? dist_update<double>(h, s.mat, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1)
-                                : dist_update<float>(h, h->fmat, s.s_upd, h->n_pad, (int)J, (int)W, (int)(J + W), (int)c0, (int)c1);
-  if (rc) return rc;
-  if (h->opt_dist_async) return SIGP_OK;
-  return sync_slot(h, s);
-}
-
-int sigp_dist_sync(sigp_handle* h, int which) {
-  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_sync: no fit in progress");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  HIPCHK(h, hipStreamSynchronize(s.s_pan));
-  if (which == 0) HIPCHK(h, hipStreamSynchronize(s.s_upd));
-  return SIGP_OK;
-}
-
-int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var) {
-  if (!h || !out || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_finish: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  int rc;
-  if (h->dtype == SIGP_F32) {
-    // every rank holds the whole fp32 factor: the fp64 refinement runs replicated, no further exchange
-    if (info != 0) {
-      finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
-    } else {
-      if ((rc = f32_finish(h, h->kernel_id, h->ell, h->sn_tilde, h->X, h->y, h->Xs, h->n, h->d, h->dp, h->n_pad, h->m, out, mean, var))) return rc;
-      info = (int64_t)out[2];
-    }
-  } else {
-    if ((rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m))) return rc;
-    if ((rc = sync_slot(h, s))) return rc;
-    h->fit_res.assign(s.res_host, s.res_host + 512);
-    finish_results(s.res_host, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
-  }
-  h->built = false;
-  h->factored = h->fitted = (info == 0);
-  h->sigma_f = out[0]; h->nlml = out[1];
-  if (info != 0) return fail(h, SIGP_NOT_SPD, "dist_finish: matrix is not positive definite (pivot %d)", (int)info);
-  return SIGP_OK;
-}
-
-// ---- one large fit sharded over GPUs, OWNER-ONLY storage: a rank allocates, builds and updates only the block columns of the
-// panels it owns; a received panel is used straight out of the receive buffer (no unpack), and the ride-row reductions are
-// partial sums the host all-reduces.  (sigp_dist_* above is the replicated form: every rank ends up with the whole factor.)
-static double* dl_origin(sigp_handle* h, int q) {      // virtual origin of panel q's columns: element (i, j) = origin[i * ncol + j], j global
-  return h->dl.mat + h->dl.lcol[(size_t)q] - (long)q * h->dl.W * NB;
-}
-static int dl_width(const sigp_handle* h, int q) { return (int)std::min<long>(h->dl.W, h->n_pad / NB - (long)q * h->dl.W); }
-
-int sigp_dist_local_begin(sigp_handle* h, int64_t W, int64_t world, int64_t rank) {
-  if (!h || h->n == 0) return fail(h, SIGP_BAD_ARG, "dist_local_begin: call set_train first");
-  if (h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "dist_local_begin: fp64 engine only (the fp32 refinement needs the whole factor on every rank)");
-  if (W < 1 || W > 64 || world < 1 || rank < 0 || rank >= world) return fail(h, SIGP_BAD_ARG, "dist_local_begin: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  auto& dl = h->dl;
-  const long T = h->n_pad / NB;
-  dl.W = (int)W; dl.world = (int)world; dl.rank = (int)rank; dl.P = (int)((T + W - 1) / W);
-  dl.lcol.assign((size_t)dl.P, -1);
-  long ncol = 0;
-  for (int q = 0; q < dl.P; ++q)
-    if (q % dl.world == dl.rank) { dl.lcol[(size_t)q] = ncol; ncol += (long)dl_width(h, q) * NB; }
-  dl.ncol = std::max<long>(ncol, NB);
-  const long need = (h->n_pad + RIDE) * dl.ncol;
-  if (dl.cap < need) {
-    HIPCHK(h, hipDeviceSynchronize());
-    if (dl.mat) HIPCHK(h, hipFree(dl.mat));
-    dl.mat = nullptr; dl.cap = 0;
-    HIPCHK(h, hipMalloc((void**)&dl.mat, (size_t)need * sizeof(double)));
-    dl.cap = need;
-  }
-  if (dl.cap_dinv < T * NB * NB) {
-    if (dl.dinv) HIPCHK(h, hipFree(dl.dinv));
-    dl.dinv = nullptr; dl.cap_dinv = 0;
-    HIPCHK(h, hipMalloc((void**)&dl.dinv, (size_t)(T * NB * NB) * sizeof(double)));
-    dl.cap_dinv = T * NB * NB;
-  }
-  HIPCHK(h, hipMemset(dl.dinv, 0, (size_t)(T * NB * NB) * sizeof(double)));     // strictly-upper parts stay zero
-  for (int k = 0; k < 2; ++k) {
-    if (!dl.ev_buf[k]) HIPCHK(h, hipEventCreateWithFlags(&dl.ev_buf[k], hipEventDisableTiming));
-    dl.ev_set[k] = false;
-  }
-  Slot& s = h->slots[0];
-  HIPCHK(h, hipFuncSetAttribute((const void*)potrf_diag_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, DIAG_LDS_BYTES));
-  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), s.s_upd));
-  HIPCHK(h, hipDeviceSynchronize());
-  dl.on = true;
-  h->built = h->factored = h->fitted = false;
-  return SIGP_OK;
-}
-
-int sigp_dist_local_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma) {
-  if (!h || !h->dl.on) return fail(h, SIGP_BAD_ARG, "dist_local_build: call dist_local_begin first");
-  if (!(sn_tilde >= 0)) return fail(h, SIGP_BAD_ARG, "sn_tilde >= 0 required");
-  HIPCHK(h, hipSetDevice(h->device));
-  auto& dl = h->dl;
-  Slot& s = h->slots[0];
-  hipStream_t st = s.s_upd;
-  const long n = h->n, n_pad = h->n_pad, dp = h->dp;
-  int rc;
-  h->kernel_id = kernel_id; h->sn_tilde = sn_tilde;
-  if (kernel_id == SIGP_KERNEL_NETDIFFUSION) {
-    if (!Sigma || ldsigma < h->d) return fail(h, SIGP_BAD_ARG, "dist_local_build: Sigma required for the reference kernel");
-    h->kp = make_kparams(SIGP_KERNEL_NETDIFFUSION, 1.0, sn_tilde, 0); h->ell = 0;
-    if ((rc = sigma_prepare(h, Sigma, ldsigma))) return rc;
-    for (int q = 0; q < dl.P; ++q)
-      if (dl.lcol[(size_t)q] >= 0 && (rc = sigma_emit(h, dl_origin(h, q), dl.ncol, q * dl.W, q * dl.W + dl_width(h, q), sn_tilde))) return rc;
-    if ((rc = sigma_kss(h, Sigma, ldsigma))) return rc;
-  } else {
-    if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "bad kernel_id");
-    if (!(ell > 0)) return fail(h, SIGP_BAD_ARG, "ell > 0 required");
-    h->kp = make_kparams(kernel_id, ell, sn_tilde, 0); h->ell = ell;
-    h->kss_unit.assign((size_t)h->m, 1.0);
-    s.kps_host[0] = h->kp;
-    if ((rc = upload_kparams(h, s, 1))) return rc;
-    for (int q = 0; q < dl.P; ++q) {
-      if (dl.lcol[(size_t)q] < 0) continue;
-      const int Wq = dl_width(h, q), J = q * dl.W;
-      double* vo = dl_origin(h, q);
-      ProfScope ps(h, st, SIGP_KC_KBUILD, (double)n * Wq * NB * (3.0 * h->d + 20), 8.0 * n * Wq * NB);
-      hipLaunchKernelGGL(kbuild_kernel<double>, dim3((unsigned)Wq, (unsigned)(n_pad / KB_TM), 1), dim3(256), 0, st, h->X, 0L, (int)dp, (int)h->d, (int)n, vo, 0L,
-                         dl.ncol, s.kps, 8, J);
-      hipLaunchKernelGGL(ride_build_kernel<double>, dim3((unsigned)((Wq * NB + 255) / 256), RIDE, 1), dim3(256), 0, st, h->X, 0L, h->Xs, 0L, h->y, 0L, (int)dp,
-                         (int)h->d, (int)n, (int)n_pad, (int)h->m, 1, vo + n_pad * dl.ncol, 0L, dl.ncol, s.kps, 1, J * NB, Wq * NB);
-      HIPCHK(h, hipGetLastError());
-    }
-  }
-  HIPCHK(h, hipMemsetAsync(s.info, 0, sizeof(int), st));
-  if ((rc = sync_slot(h, s))) return rc;
-  return SIGP_OK;
-}
-
-int64_t sigp_dist_local_owner(sigp_handle* h, int64_t p) { return (h && h->dl.on && p >= 0 && p < h->dl.P) ? p % h->dl.world : -1; }
-int64_t sigp_dist_local_panels(sigp_handle* h) { return (h && h->dl.on) ? h->dl.P : 0; }
-
-// owner of panel p: factor it in place (local storage), pack [rows from its diagonal block down x its columns | its inverse
-// diagonal blocks] into dev_buf (sigp_dist_panel_elems(h, p*W, width) elements) and return the LAPACK info so far
-int sigp_dist_local_factor(sigp_handle* h, int64_t p, void* dev_buf, int64_t* info) {
-  if (!h || !h->dl.on || p < 0 || p >= h->dl.P || !dev_buf) return fail(h, SIGP_BAD_ARG, "dist_local_factor: bad argument");
-  auto& dl = h->dl;
-  if (dl.lcol[(size_t)p] < 0) return fail(h, SIGP_BAD_ARG, "dist_local_factor: panel %ld belongs to rank %ld", (long)p, (long)(p % dl.world));
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  hipStream_t sp = h->opt_dist_async ? s.s_pan : s.s_upd;
-  if (h->opt_dist_async) HIPCHK(h, hipStreamWaitEvent(sp, s.ev_la, 0));
-  const int Wp = dl_width(h, (int)p), J = (int)p * dl.W;
-  int rc = dist_panel<double>(h, s, dl_origin(h, (int)p), dl.ncol, dl.dinv, sp, h->n_pad, J, Wp);
-  if (rc) return rc;
-  const long rows = h->n_pad + RIDE - (long)J * NB, wcols = (long)Wp * NB;
-  double* buf = (double*)dev_buf;
-  HIPCHK(h, hipMemcpy2DAsync(buf, (size_t)wcols * sizeof(double), dl.mat + (long)J * NB * dl.ncol + dl.lcol[(size_t)p], (size_t)dl.ncol * sizeof(double),
-                             (size_t)wcols * sizeof(double), (size_t)rows, hipMemcpyDeviceToDevice, sp));
-  HIPCHK(h, hipMemcpyAsync(buf + rows * wcols, dl.dinv + (long)J * NB * NB, (size_t)Wp * NB * NB * sizeof(double), hipMemcpyDeviceToDevice, sp));
-  HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, sp));
-  if (h->opt_dist_async) {
-    HIPCHK(h, hipEventRecord(s.ev_pan, sp));
-    HIPCHK(h, hipStreamWaitEvent(s.s_upd, s.ev_pan, 0));
-  }
-  HIPCHK(h, hipStreamSynchronize(sp));       // REQUIRED: the caller hands dev_buf to a collective on another stream next
-  if (info) *info = *s.info_host;
-  return SIGP_OK;
-}
-
-// own panel q (> p) -= (panel p)(panel p)^T, panel p read straight from the packed buffer (its owner reads its own pack too).
-// buf_slot (0/1): which receive buffer dev_buf is, for sigp_dist_local_buffer_wait.
-int sigp_dist_local_update(sigp_handle* h, int64_t p, const void* dev_buf, int64_t q, int buf_slot) {
-  if (!h || !h->dl.on || p < 0 || q <= p || q >= h->dl.P || !dev_buf || buf_slot < 0 || buf_slot > 1) return fail(h, SIGP_BAD_ARG, "dist_local_update: bad argument");
-  auto& dl = h->dl;
-  if (dl.lcol[(size_t)q] < 0) return fail(h, SIGP_BAD_ARG, "dist_local_update: panel %ld is not this rank's", (long)q);
-  HIPCHK(h, hipSetDevice(h->device));
-  Slot& s = h->slots[0];
-  const int Wp = dl_width(h, (int)p), Jp = (int)p * dl.W, Wq = dl_width(h, (int)q), Jq = (int)q * dl.W;
-  const int R = (int)(h->n_pad / NB) + 1;
-  const long lda = (long)Wp * NB, o = (long)Jq * NB;
-  GemmArgs g{};
-  g.A = (const double*)dev_buf + (o - (long)Jp * NB) * lda; g.lda = lda;       // rows of panel p from row block Jq down
-  g.B = g.A; g.ldb = lda;
-  g.C = dl_origin(h, (int)q) + o * dl.ncol + o; g.ldc = dl.ncol;
-  g.batch = 1; g.K = Wp * NB; g.r0 = 0; g.r1 = R - Jq; g.c0 = 0; g.c1 = Wq; g.lower = 1;
-  int rc = gemm_sub_auto(h, s.s_upd, g);
-  if (rc) return rc;
-  HIPCHK(h, hipEventRecord(dl.ev_buf[buf_slot], s.s_upd));
-  dl.ev_set[buf_slot] = true;
-  if (h->opt_dist_async) return SIGP_OK;
-  return sync_slot(h, s);
-}
-
-// block until every update that reads receive buffer `buf_slot` has finished (before the next panel is received into it)
-int sigp_dist_local_buffer_wait(sigp_handle* h, int buf_slot) {
-  if (!h || !h->dl.on || buf_slot < 0 || buf_slot > 1) return fail(h, SIGP_BAD_ARG, "dist_local_buffer_wait: bad argument");
-  if (h->dl.ev_set[buf_slot]) HIPCHK(h, hipEventSynchronize(h->dl.ev_buf[buf_slot]));
-  return SIGP_OK;
-}
-
-// partial reductions over this rank's columns: res [512] laid out as epilogue_kernel's (the host sums them over the ranks)
-int sigp_dist_local_reduce(sigp_handle* h, double* res) {
-  if (!h || !h->dl.on || !res) return fail(h, SIGP_BAD_ARG, "dist_local_reduce: bad argument");
-  HIPCHK(h, hipSetDevice(h->device));
-  auto& dl = h->dl;
-  Slot& s = h->slots[0];
-  hipStream_t st = s.s_upd;
-  HIPCHK(h, hipStreamSynchronize(s.s_pan));
-  HIPCHK(h, hipMemsetAsync(s.res, 0, 512 * sizeof(double), st));
-  bool any = false;
-  for (auto c : dl.lcol) any = any || c >= 0;
-  if (any) {
-    const double* Z = dl.mat + h->n_pad * dl.ncol;
-    hipLaunchKernelGGL(epilogue_kernel<double>, dim3((unsigned)(h->m + 1), 1), dim3(256), 0, st, Z, dl.ncol, Z, (const double*)nullptr, dl.ncol, (int)h->n,
-                       (int)dl.ncol, (int)(h->m + 1), s.res, 0L, 0L, 0L);
-    for (int q = 0; q < dl.P; ++q)
-      if (dl.lcol[(size_t)q] >= 0)
-        hipLaunchKernelGGL(logdiag_window_kernel, dim3(1), dim3(256), 0, st, (const double*)dl_origin(h, q), dl.ncol, (int)h->n, q * dl.W * NB, dl_width(h, q) * NB, s.res + 256);
-    HIPCHK(h, hipGetLastError());
-  }
-  HIPCHK(h, hipMemcpyAsync(s.res_host, s.res, 512 * sizeof(double), hipMemcpyDeviceToHost, st));
-  HIPCHK(h, hipStreamSynchronize(st));
-  memcpy(res, s.res_host, 512 * sizeof(double));
-  return SIGP_OK;
-}
-
-// res = the ranks' partial reductions summed: sigma_f, nlML, predictions as sigp_fit_predict's out / mean / var
-int sigp_dist_local_results(sigp_handle* h, const double* res, int64_t info, double* out, double* mean, double* var) {
-  if (!h || !h->dl.on || !res || !out) return fail(h, SIGP_BAD_ARG, "dist_local_results: bad argument");
-  finish_results(res, (int)info, h->n, h->m, h->sn_tilde, h->kss_unit.data(), out, mean, var);
-  h->sigma_f = out[0]; h->nlml = out[1];
-  h->built = h->factored = h->fitted = false;      // the factor is spread over the ranks: no general predict / alpha on this handle
-  if (info != 0) return fail(h, SIGP_NOT_SPD, "dist_local_results: matrix is not positive definite (pivot %d)", (int)info);
-  return SIGP_OK;
-}
+#include "sigp_dist.inc"      // sigp_dist_*, sigp_dist_local_*
 
 int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return SIGP_BAD_ARG;
