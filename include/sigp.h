@@ -253,7 +253,8 @@ int sigp_profile_reset(sigp_handle* h);
  *   tile walks of the trailing update -- placement only, results bit-identical; all measured slower than the default and left off
  *   (DESIGN.md section 7):  xcd_chunks [0] (P: 64-tile chunks of PxP patches per XCD), update_wgs [0] (persistent grid of this many
  *   workgroups) with update_late [0] (only for the last k panels), pipeline_head [0] (two lockstep groups in flight: 1 = only the next
- *   group's build + first panel overlap the current group, 2 = only its build), small_nt64 [0] (one wavefront per fit in sigp_small_run),
+ *   group's build + first panel overlap the current group, 2 = only its build, 3 = the head starts when the current group has head_gate
+ *   [16] block columns left), small_nt64 [0] (one wavefront per fit in sigp_small_run),
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it)
  *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [3] (bit 0: panels that are not strip-solved,
  *   bit 1: top blocks of strip-solved panels, are factored column by column with the other columns' update riding in the diagonal-block

@@ -50,6 +50,7 @@ struct Slot {
   hipStream_t s_upd = nullptr, s_pan = nullptr;
   hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
   hipEvent_t ev_group = nullptr;   // recorded on s_upd when a lockstep group has finished (head pipelining of the next group)
+  hipEvent_t ev_tail = nullptr;    // recorded on s_pan when a group enters its tail (pipeline_head = 3: the next group's head starts there)
 };
 
 }  // namespace
@@ -149,6 +150,7 @@ struct sigp_handle {
                                      // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion
   int opt_chain_rows = 80;           // (see panel_any)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
+  int opt_head_gate = 16;    // pipeline_head = 3: a group's tail begins when at most this many block columns remain behind the panel just enqueued
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)
   int opt_update_late = 0;   // with update_wgs: only the outer updates of the last `update_late` panels run persistent (0 = all outer updates)
@@ -227,6 +229,7 @@ int slot_init(sigp_handle* h, Slot& s) {
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_la, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
   HIPCHK(h, hipEventCreateWithFlags(&s.ev_group, hipEventDisableTiming));
+  HIPCHK(h, hipEventCreateWithFlags(&s.ev_tail, hipEventDisableTiming));
   return SIGP_OK;
 }
 
@@ -276,6 +279,7 @@ void slot_free(Slot& s) {
   if (s.ev_la) (void)hipEventDestroy(s.ev_la);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
   if (s.ev_group) (void)hipEventDestroy(s.ev_group);
+  if (s.ev_tail) (void)hipEventDestroy(s.ev_tail);
   if (s.s_upd) (void)hipStreamDestroy(s.s_upd);
   if (s.s_pan) (void)hipStreamDestroy(s.s_pan);
   s = Slot();
@@ -700,11 +704,16 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     return SIGP_OK;
   }
   bool have_rest = false;                      // first_on_panel: an update of the rest of the trailing matrix is in flight on su
+  bool tail_marked = false;                    // ev_tail recorded (pipeline_head = 3)
   for (int J = 0; J < T; J += W) {
     const int Wc = std::min(W, T - J);
     const int ncols = T - (J + Wc);            // trailing column blocks
     if (ncols <= 0) break;
     const int Wn = std::min(W, ncols);         // width of the next panel
+    if (la && !tail_marked && ncols <= h->opt_head_gate) {   // panel J is the last one before the tail: the next group's head may start behind it
+      HIPCHK(h, hipEventRecord(s.ev_tail, sp));
+      tail_marked = true;
+    }
     if (la && (h->opt_first_on_panel == 2 || (h->opt_first_on_panel == 1 && !use_strips(J + Wc, Wn)))) {
       // The update of the NEXT panel's columns stays on the panel stream (stream order, no inter-queue hand-off in the chain
       // panel -> first update -> next panel: each hand-off is a barrier packet pair, 11-13 us measured); the update stream gets
@@ -754,6 +763,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     }
   }
   if (la) {   // join: the update stream is the slot's completion stream
+    if (!tail_marked) HIPCHK(h, hipEventRecord(s.ev_tail, sp));
     HIPCHK(h, hipEventRecord(s.ev_pan, sp));
     HIPCHK(h, hipStreamWaitEvent(su, s.ev_pan, 0));
   }
@@ -1104,7 +1114,8 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
-  if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "head_gate")) { if (value < 0) return SIGP_BAD_ARG; h->opt_head_gate = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_late")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_late = (int)value; return SIGP_OK; }
   if (!strcmp(name, "update_wgs")) { if (value < 0 || value > 4096) return SIGP_BAD_ARG; h->opt_update_wgs = (int)value; return SIGP_OK; }
   if (!strcmp(name, "group")) { if (value < 1 || value > 256) return SIGP_BAD_ARG; h->opt_group = (int)value; return SIGP_OK; }
@@ -1703,6 +1714,9 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     // ~8 % of a step); its update stream waits for group g-1 to finish, so the bulk of two groups never competes
     const bool head = h->opt_pipeline_head && nslots >= 2 && h->opt_lookahead && h->opt_schedule == 0;
     if (head && g > 0) HIPCHK(h, hipStreamWaitEvent(s.s_upd, h->slots[(g - 1) % nslots].ev_group, 0));
+    // pipeline_head = 3: the head does not start as soon as it is enqueued (that is the bulk of group g-1, where the chip is
+    // saturated anyway) but when group g-1 enters its tail -- its last panels, where the update stream runs dry
+    if (head && h->opt_pipeline_head == 3 && g > 0) HIPCHK(h, hipStreamWaitEvent(s.s_pan, h->slots[(g - 1) % nslots].ev_tail, 0));
     hipStream_t sb = head ? s.s_pan : s.s_upd;
     if ((rc = upload_kparams(h, s, nb, sb))) return rc;
     if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m, sb))) return rc;
