@@ -7,7 +7,9 @@ kernel-matrix build -> blocked Cholesky (with y and the test point riding along)
 mean/variance at m=1 for each.  The metric stays GP fits/sec (= 40 x steps / time).  Inputs (the years' X, y, Xs)
 are resident in HBM before the timed region.
 
-N > 1 (one process per GPU, RCCL for the barrier / max-reduce only -- independent fits need no data-path collective):
+N > 1 (one process per GPU, RCCL for the barrier / max-reduce only -- independent fits need no data-path collective; AFTER the
+metric the same ranks run BASELINE configs[3] / [4] as ONE fit sharded over all of them -- the library's own RCCL communicator,
+block-row panel broadcast -- and rank 0 adds the untimed "sharded" record to the line):
   --scaling weak   (default) every rank holds its own 40 years and runs the same number of steps: per-GPU work fixed
   --scaling strong the fixed job (steps x 40 fits) is dealt round-robin over the ranks (a rank's lockstep groups then mix
                    years and grid points)
@@ -103,7 +105,9 @@ def main():
     ap.add_argument("--host-timing", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-reps", type=int, default=1, help="timed CPU repetitions at n=8192 (48 s each in the reference idiom; n=64 and n=4096 always run 1 warm-up + 3)")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed CPU repetitions at n=8192 after one warm-up (BASELINE.md section 2 protocol: 1 + 3, median; ~48 s each in the reference idiom); 1 = one cold fit")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the untimed sharded configs[3]/[4] record")
+    ap.add_argument("--sharded-timeout", type=float, default=240.0, help="N > 1: seconds after which the line is printed without the sharded record")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel HIP-event brackets")
     ap.add_argument("--no-extras", action="store_true", help="skip the untimed extra records (other configs, MLII, reference-kernel grid)")
     args = ap.parse_args(json.loads(os.environ["SIGP_BENCH_ARGV"]) if len(sys.argv) == 1 and "SIGP_BENCH_ARGV" in os.environ else None)
@@ -196,6 +200,14 @@ def main():
     barrier()
     prof = gp.profile_get()
     gp.profile(False)
+    unbracketed = None
+    if not args.no_profile and not args.no_extras:
+        # the same steps once more WITHOUT the per-launch HIP-event brackets of the dominant kernel (`value` carries them)
+        barrier(); ta = time.perf_counter()
+        gp.run_batch(W, K, ell[W:], sn[W:], concurrency=args.concurrency, group=args.group)
+        torch.cuda.synchronize(); tub = time.perf_counter() - ta
+        barrier()
+        unbracketed = tub
     prof_all = None
     if not args.no_profile and rank == 0:
         # per-kernel breakdown from one extra, untimed group with every launch bracketed
@@ -238,9 +250,11 @@ def main():
         m64 = {"value": k64 / tb64, "unit": "fits/s", "steps": k64, "note": "same workload with m=64 test points per fit (ride-along rows), measured after the timed region"}
     elapsed = t1 - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed, unbracketed or 0.0], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if unbracketed is not None:
+            unbracketed = float(t[1].item())
     assert np.all(r["info"] == 0) and np.all(np.isfinite(r["mean"]))
 
     fits = args.steps * G * (world if args.scaling == "weak" else 1)       # whole-job timed fits
@@ -266,6 +280,9 @@ def main():
     }
     if m64 is not None:
         out["m64"] = m64
+    if unbracketed is not None:
+        out["without_event_brackets"] = {"value": fits / unbracketed, "unit": "fits/s",
+                                         "note": "the same timed steps run once more with no HIP-event brackets around the dominant kernel (untimed extra; `value` is measured WITH them, as the roofline needs)"}
     if rank == 0:
         dom = prof["syrk128"]
         if dom["launches"] and dom["ms"] > 0:
@@ -280,15 +297,21 @@ def main():
             # HBM-side traffic of the same kernel is NOT measured in this run: it comes from separate rocprofv3 --pmc passes of this
             # command (FETCH_SIZE / WRITE_SIZE cannot share a pass, and PMC collection serialises kernels), summarised under
             # profiles/ by tools/collect_profiles.sh + tools/summarize_pmc.py
-            for rnd in ("r02", "r01"):
+            # ... and quoted only when the file was collected from THIS kernel code (sha of the csrc files recorded at collection time)
+            for rnd in ("r03", "r02"):
                 pth = os.path.join(ROOT, "profiles", "%s_pmc_syrk128.json" % rnd)
                 if not os.path.exists(pth):
                     continue
                 try:
                     pm = json.load(open(pth))
                     if n == 8192 and d == 8 and args.group == 40 and args.outer == 8:
-                        out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                        out["roofline"]["traffic_source"] = "from profiles/%s_pmc_syrk128.json (rocprofv3 --pmc passes of this command, NOT this run): bytes per launch = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % rnd
+                        if pm.get("kernel_code_sha16") == kernel_code_sha16():
+                            out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                            out["roofline"]["traffic_source"] = ("from profiles/%s_pmc_syrk128.json (rocprofv3 --pmc passes of this command on this kernel code, sha16 %s; NOT this run): "
+                                                                 "bytes per launch = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE" % (rnd, pm["kernel_code_sha16"]))
+                        else:
+                            out["roofline"]["traffic_source"] = ("profiles/%s_pmc_syrk128.json was collected from other kernel code (sha16 %s, now %s): not quoted"
+                                                                 % (rnd, pm.get("kernel_code_sha16"), kernel_code_sha16()))
                         out["roofline"]["algorithmic_c_bytes_per_launch"] = dom["bytes"] / dom["launches"]
                 except Exception:
                     pass
@@ -310,10 +333,111 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, len(my_years), r, local)
+        if out.get("cpu_baseline", {}).get("value"):
+            out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]     # (vs_baseline stays null: the reference publishes no number for this metric)
+    if world > 1 and not args.no_sharded:
+        # ONE fit sharded over all ranks (configs[3], configs[4]): untimed record.  A watchdog prints the metric line without it if a
+        # collective hangs -- nothing after the timed region may cost the line.
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["sharded"] = {"error": "no result within %.0f s (watchdog)" % args.sharded_timeout}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        wd = threading.Timer(args.sharded_timeout, give_up)
+        wd.daemon = True
+        wd.start()
+        try:
+            rec = sharded_record(rank, world, local, dist, backend)
+        except Exception as e:                   # noqa: BLE001
+            rec = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        wd.cancel()
+        if rank == 0:
+            out["sharded"] = rec
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def kernel_code_sha16():
+    """sha256 (first 16 hex digits) of the device code the roofline kernel is compiled from."""
+    import hashlib
+    hs = hashlib.sha256()
+    csrc = os.path.join(ROOT, "seaiceextentforecasting_amd", "csrc")
+    for f in ("syrk128.hpp", "gemm_mfma.hpp", "potrf_diag.hpp"):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            hs.update(fh.read())
+    return hs.hexdigest()[:16]
+
+
+def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "configs[4]"), reps=3, outer=8):
+    """BASELINE configs[3] (n=16384, d=16 fp64 RBF) and configs[4] (n=32768, d=32 fp32 Matern-5/2 + fp64 refinement) as ONE fit
+    sharded over all `world` ranks: the library's own sharded fit (sigp_dist_fit: block-cyclic panels, panel broadcast on the
+    library's RCCL communicator with look-ahead; fp32: solves on the distributed factor, residual sharded by rows).  Every rank
+    calls this; rank 0 returns the record.  Time per fit = max over ranks of the best of `reps` (after one warm-up fit)."""
+    import torch
+    from seaiceextentforecasting_amd import DistributedGPR, GPR
+    shapes = {"configs[3]": ("rbf", "f64", 16384, 16, 4.0, 1e-2, 20240003, PEAK_F64_MFMA_TFLOPS),
+              "configs[4]": ("matern52", "f32", 32768, 32, float(np.sqrt(32.0)), 1e-1, 20240004, PEAK_F32_MFMA_TFLOPS)}
+    rec = {}
+    dev = "cuda" if backend == "nccl" else "cpu"
+    for tag in configs:
+        kind, dtype, n, d, ell, sn, seed, peak = shapes[tag]
+        X, y, Xs = synthetic_problem(n, d, seed, m=1)
+        with DistributedGPR(kind, rank, world, dist, device=local, outer_blocks=outer, dtype=dtype, stats=True) as dg:
+            times = []
+            dg.fit(X, y, ell, sn, Xs=Xs)          # stages X, y, Xs on every rank, allocates, opens the ring
+            for r_ in range(reps + 1):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                dg.refit(ell, sn)
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if dist is not None:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if r_ > 0:
+                    times.append(float(t.item()))
+            st = dg.stats()
+            mu, var = dg.predict(Xs)
+            res = dict(sigma_f=dg.sigma_f_, nlml=dg.nlml_, mean=float(mu[0]), var=float(var[0]), matrix_bytes=dg.matrix_bytes_, transport=dg.transport)
+            if dtype == "f32":
+                res["refinement_residual"] = dg.refine_residual_
+        # per-rank numbers worth a max / sum over the ranks
+        v = torch.tensor([st["stall_ms"], st["comm_ms"], st["factor_ms"], st["solve_ms"], res["matrix_bytes"]], dtype=torch.float64, device=dev)
+        vmax = v.clone()
+        if dist is not None:
+            dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
+        best = min(times)
+        e = {"workload": "%s: n=%d d=%d %s %s, ONE fit sharded over %d rank(s): 1-D block-cyclic panels of %d x 128 columns, owner-only storage" % (tag, n, d, dtype, kind, world, outer),
+             "transport": ("library RCCL communicator (ncclCommCount = %d)" % int(st["comm_ranks"])) if res["transport"] == "rccl" else res["transport"],
+             "ms_per_fit": 1e3 * best, "ms_per_fit_all": [round(1e3 * t, 3) for t in times], "fits_per_s": 1.0 / best,
+             "tflops": flops_per_fit(n, d) / best / 1e12, "frac_of_peak_all_gpus": flops_per_fit(n, d) / best / 1e12 / (peak * world),
+             "panel_broadcast_bytes_per_fit": st["bcast_bytes"], "collectives_per_fit": st["collectives"],
+             "max_over_ranks_ms": {"update_stream_stalled_on_a_panel": float(vmax[0]), "broadcasts_in_flight": float(vmax[1]), "panel_loop_device_time": float(vmax[2]),
+                                   "reductions_solves_refinement_host_time": float(vmax[3])},
+             "broadcast_hidden_by_lookahead": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
+             "matrix_bytes_max_rank": float(vmax[4]), "sigma_f": res["sigma_f"], "nlml": res["nlml"], "mean": res["mean"], "var": res["var"]}
+        if "refinement_residual" in res:
+            e["refinement_residual"] = res["refinement_residual"]
+        if rank == 0:
+            # the same fit through the single-GPU entry point on rank 0's GPU: what the sharded numbers are checked and priced against
+            with GPR(kernel=kind, dtype=dtype, device=local) as g1:
+                g1.fit(X, y, ell, sn, Xs=Xs)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                g1.refit(ell, sn)
+                torch.cuda.synchronize(); t1 = time.perf_counter() - t0
+                m1, v1 = g1.predict(Xs)
+                e["single_gpu"] = {"ms_per_fit": 1e3 * t1, "speedup_of_sharded": t1 / best,
+                                   "rel_diff_mean": float(abs(res["mean"] - m1[0]) / abs(m1[0])), "rel_diff_var": float(abs(res["var"] - v1[0]) / abs(v1[0])),
+                                   "rel_diff_nlml": float(abs(res["nlml"] - g1.nlml_) / abs(g1.nlml_))}
+        if dist is not None:
+            dist.barrier()
+        rec[tag] = e
+    return rec if rank == 0 else None
 
 
 def timed(fn, reps, warm=1):

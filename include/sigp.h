@@ -46,6 +46,9 @@ enum { SIGP_KC_KBUILD = 0, SIGP_KC_DIAG = 1, SIGP_KC_TRSM = 2, SIGP_KC_UPDATE_SM
 #define SIGP_MAX_RIDE 127 /* test points that can ride along one factorisation */
 
 int sigp_version(void);
+/* "HIP runtime <version> (<status>) from <path of the libamdhip64 that serves this process>" -- for error reports: a process that
+ * also loads PyTorch-ROCm has two HIP runtimes on disk, and whichever is mapped first serves everyone. */
+int sigp_runtime_info(char* buf, int64_t len);
 
 /* lifetime ------------------------------------------------------------------------------------ */
 int sigp_create(sigp_handle** h, int device_id, int dtype);
@@ -161,7 +164,7 @@ double sigp_host_nanmean(const double* a, int64_t n);
 int sigp_detrend(sigp_handle* h, const double* data, int64_t P, int64_t T, int64_t ncuts, const int64_t* cut_len, double* dt_out, double* trend_out);
 
 /* named scalars of the last operation: "refine_residual" (fp32 engine: max|y - K~ alpha~| / max|y| after the last refinement
- * step), "matrix_bytes" (device bytes held by this handle's matrix / factor buffers). */
+ * step), "matrix_bytes" (device bytes held by this handle's matrix / factor buffers), "dist_*" (see sigp_dist_fit). */
 int sigp_get_stat(sigp_handle* h, const char* name, double* value);
 
 /* K7 (explicit): alpha~ = K~^-1 y  [n]  (north/June1st.py:266; alpha of :271 is alpha~/sigma_f). */
@@ -176,60 +179,53 @@ int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo);
 int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma,
                    const double* MSigma, int64_t ldsigma, int grad_mode, double* nlml, double grad[2]);
 
-/* One large fit sharded over GPUs (BASELINE configs[3]): 1-D block-cyclic ownership of outer panels
- * (W column blocks of 128); the host side (dist.DistributedGPR) moves factored panels between ranks with
- * torch.distributed (RCCL broadcast over xGMI on the GPU box).  Every rank holds the whole matrix buffer but
- * only updates the panels it owns; a factored panel is packed into a contiguous device buffer, broadcast,
- * and unpacked by the other ranks.  J, W, c0, c1 are in units of 128-column blocks.
- * Replaces the same np.linalg.cholesky call (north/June1st.py:265) as sigp_potrf.
- * Transport: this ABI deliberately has NO sigp_dist_init(nranks, rank, nccl_id) -- the library never opens an RCCL communicator of
- * its own.  One process per GPU already owns one (torch.distributed, backend "nccl" = RCCL over xGMI), and a second communicator
- * per process would only duplicate rings and bootstrap; so the library exposes the panel as a contiguous DEVICE buffer
- * (sigp_dist_panel_pack / _unpack) and stream-ordering hooks (sigp_dist_mark / _sync), and the caller moves that buffer with whatever
- * collective it owns -- dist.DistributedGPR uses torch.distributed.broadcast(async_op=True); a C caller would hand the same pointer to
- * ncclBroadcast.  sigp_dist_panel_pack returns only after the pack has completed on the library's private stream
- * (hipStreamSynchronize) and the host side waits for the collective before sigp_dist_panel_unpack: both synchronisations are REQUIRED,
- * they are what orders the library's non-blocking streams against the collective's stream.
- * Works for both engines: on an fp32 handle (BASELINE configs[4]) sigp_kernel_build builds the fp32 matrix, the panels
- * travel as fp32 (dev_buf holds floats) and sigp_dist_finish runs the fp64 iterative refinement on every rank. */
-int sigp_dist_begin(sigp_handle* h);                                   /* after sigp_kernel_build*: reset info  */
-int64_t sigp_dist_panel_elems(sigp_handle* h, int64_t J, int64_t W);  /* doubles in the packed panel J..J+W     */
-int sigp_dist_panel_factor(sigp_handle* h, int64_t J, int64_t W, int64_t* info);  /* owner: factor panel       */
-int sigp_dist_panel_pack(sigp_handle* h, int64_t J, int64_t W, void* dev_buf);    /* matrix -> contiguous buf  */
-int sigp_dist_panel_unpack(sigp_handle* h, int64_t J, int64_t W, const void* dev_buf); /* buf -> matrix + dinv  */
-/* trailing update of column blocks [J+W+c0, J+W+c1) with panel J..J+W (only the caller's own panels) */
-int sigp_dist_update(sigp_handle* h, int64_t J, int64_t W, int64_t c0, int64_t c1);
-/* Look-ahead support: with sigp_set_option(h, "dist_async", 1) sigp_dist_update and sigp_dist_panel_unpack only
- * enqueue their work (unpack on the panel stream, the update stream waits for it) and return; sigp_dist_sync
- * blocks until the received panels are unpacked (which = 1: the broadcast buffer may be reused) or until all
- * enqueued work is done (which = 0).  In that mode sigp_dist_panel_factor / _pack run on the panel stream: the
- * factor starts once the update-stream work enqueued before the last sigp_dist_mark is done (the update of that
- * panel's own columns) and overlaps the updates enqueued after the mark; both still return synchronously. */
-int sigp_dist_sync(sigp_handle* h, int which);
-int sigp_dist_mark(sigp_handle* h);
-/* after the last panel: reductions + results, as sigp_fit_predict's out/mean/var; marks the handle fitted */
-int sigp_dist_finish(sigp_handle* h, int64_t info, double* out, double* mean, double* var);
+/* One large fit sharded over the GPUs of a node (BASELINE configs[3] fp64, configs[4] fp32 + fp64 refinement): 1-D block-cyclic
+ * ownership of outer panels (W column blocks of 128; panel q belongs to rank q % nranks), OWNER-ONLY storage -- a rank allocates,
+ * builds and updates only the block columns of its own panels (per-rank matrix bytes ~ 1/nranks) -- and the block-row panel
+ * broadcast inside the library: per panel the owner factors it on its panel stream, packs [rows from its diagonal block down,
+ * ride rows included] x [its columns] into a contiguous device buffer, the buffer is broadcast on a communication stream (RCCL over
+ * xGMI) while every rank is still applying the previous panel (look-ahead), and every rank updates its own later panels straight
+ * out of the buffer.  Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the
+ * pivot info is MIN-reduced once at the end together with the 512 partial ride-row reductions (the only other fp64 exchange).
+ * Replaces north/June1st.py:265 (np.linalg.cholesky) and :266-277, :246 for one large K~, as sigp_fit_predict does on one GPU.
+ * fp32 handles (SIGP_F32): the fp32 factor is sharded the same way; x = K~^-1 [y k*] then comes from triangular solves on the
+ * DISTRIBUTED factor (per panel: one skinny product with the explicit inverse of the owner's diagonal block + one skinny update
+ * of the owner's column panel, and one 16 KB collective) and the fp64 residual of the iterative refinement is sharded by rows
+ * (each rank recomputes the covariance of its rows only; one all-reduce assembles it).
+ *
+ *   sigp_dist_unique_id(id)            rank 0: a fresh 128-byte ncclUniqueId, to be handed to the other ranks by any channel
+ *   sigp_dist_init(h, nranks, rank, id)  open THIS handle's communicator on its device (collective: every rank calls it).
+ *                                      librccl is bound at run time (dlopen): a process that already has an RCCL mapped -- PyTorch-ROCm
+ *                                      ships its own -- gets that one; nranks == 1 needs no RCCL at all (id NULL; with an id a one-rank
+ *                                      communicator is opened and every collective of the fit still goes through it)
+ *   sigp_dist_init_transport(...)      instead of the library's communicator, the caller's: callbacks that move a buffer.  device_buffers
+ *                                      = 1: they receive DEVICE pointers and the hipStream_t to enqueue on (a communicator the caller
+ *                                      already owns); 0: HOST pointers (the library stages through pinned memory and synchronises per
+ *                                      collective -- rehearsal on a box with fewer GPUs than ranks, fabrics without device collectives).
+ *                                      Same panel loop, same arithmetic, same order.
+ *   sigp_dist_fit(...)                 after sigp_set_train / sigp_set_test with the SAME data on every rank (n d 8 bytes): the whole
+ *                                      sharded fit; out / mean / var as sigp_fit_predict, identical on every rank.  Sigma as there
+ *                                      (reference kernel: fp64 only).  SIGP_NOT_SPD + LAPACK pivot in out[2] on every rank otherwise.
+ *                                      The factor stays spread over the ranks: predictions exist for the ride-along points only.
+ *   set_option("owner_only", 1) before sigp_set_train keeps an fp64 handle from allocating the n x n single-GPU matrix;
+ *   set_option("dist_stats", 1) times the broadcasts with HIP events: sigp_get_stat "dist_fit_ms", "dist_factor_ms" (device time of the
+ *   panel loop), "dist_bcast_bytes", "dist_comm_ms" (sum of broadcast intervals on the communication stream), "dist_stall_ms" (time
+ *   the update stream sat idle waiting for a panel: what look-ahead did NOT hide), "dist_solve_ms", "dist_collectives". */
+typedef struct sigp_transport {
+  void* ctx;
+  int device_buffers;
+  /* broadcast `bytes` from rank `root` in place; stream: hipStream_t to order on (device_buffers) or NULL (host pointers: blocking) */
+  int (*bcast)(void* ctx, void* buf, uint64_t bytes, int root, void* stream);
+  /* all-reduce `count` elements in place; is_f32: float, else double; op 0 = sum, 1 = min.  Non-zero return = failure. */
+  int (*allreduce)(void* ctx, void* buf, uint64_t count, int is_f32, int op, void* stream);
+} sigp_transport;
+int sigp_dist_unique_id(void* id128);
+int sigp_dist_init(sigp_handle* h, int nranks, int rank, const void* nccl_id);
+int sigp_dist_init_transport(sigp_handle* h, int nranks, int rank, const sigp_transport* transport);
+int sigp_dist_fit(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma, int64_t W, int lookahead,
+                  double* out, double* mean, double* var);
+int sigp_dist_shutdown(sigp_handle* h);                                /* destroy the communicator, free the sharded storage */
 int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_pad / 128                        */
-
-/* The same sharded fit with OWNER-ONLY storage (fp64): a rank allocates, builds and updates only the block columns of the panels it
- * owns (panel q belongs to rank q % world; per-rank matrix bytes ~ 1/world), applies a received panel straight out of the receive
- * buffer (no unpack), and the ride-row reductions come back as partial sums that the caller adds over the ranks (one all-reduce of
- * 512 doubles -- the only other exchange besides the panel broadcast).  Replaces the same statements as above
- * (north/June1st.py:265-277, :246).  After the fit the factor is spread over the ranks, so only the ride-along predictions exist.
- *   set_option("owner_only", 1) before sigp_set_train keeps it from allocating the n x n slot matrix.
- *   begin(W, world, rank) -> build(kernel_id, ell, sn~, Sigma|NULL, ldsigma) -> for p in panels: owner: factor(p, buf, &info); broadcast buf;
- *   every rank: update(p, buf, q, slot) for its q > p -> reduce(res) -> all-reduce(res) -> results(res, info, out, mean, var).
- * dev_buf holds sigp_dist_panel_elems(h, p*W, width_p) doubles; with two receive buffers in rotation call buffer_wait(slot) before
- * receiving into a buffer whose previous panel may still be read by updates in flight (dist_async). */
-int sigp_dist_local_begin(sigp_handle* h, int64_t W, int64_t world, int64_t rank);
-int sigp_dist_local_build(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma);
-int64_t sigp_dist_local_panels(sigp_handle* h);
-int64_t sigp_dist_local_owner(sigp_handle* h, int64_t p);
-int sigp_dist_local_factor(sigp_handle* h, int64_t p, void* dev_buf, int64_t* info);
-int sigp_dist_local_update(sigp_handle* h, int64_t p, const void* dev_buf, int64_t q, int buf_slot);
-int sigp_dist_local_buffer_wait(sigp_handle* h, int buf_slot);
-int sigp_dist_local_reduce(sigp_handle* h, double* res);
-int sigp_dist_local_results(sigp_handle* h, const double* res, int64_t info, double* out, double* mean, double* var);
 
 /* measurement ---------------------------------------------------------------------------------- */
 /* enable=1: bracket every kernel launch with HIP events on the stream it is launched on and
@@ -248,8 +244,7 @@ int sigp_profile_reset(sigp_handle* h);
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
- *   dist_async [0]        sharded Cholesky: sigp_dist_update / _unpack / _local_update return without a host sync (see sigp_dist_sync)
- *   owner_only [0]        sigp_set_train does not allocate the n x n slot matrix (sigp_dist_local_*)
+ *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit
  *   tile walks of the trailing update -- placement only, results bit-identical; all measured slower than the default and left off
  *   (DESIGN.md section 7):  xcd_chunks [0] (P: 64-tile chunks of PxP patches per XCD), update_wgs [0] (persistent grid of this many
  *   workgroups) with update_late [0] (only for the last k panels), pipeline_head [0] (two lockstep groups in flight: 1 = only the next

@@ -224,6 +224,42 @@ def fit_predict(X, y, Xs, ell, sn_tilde, *, kind="netdiffusion", M=None, ref_idi
     return out
 
 
+def fit_predict_lean(X, y, Xs, ell, sn_tilde, *, kind="rbf", row_block=1024, threads=16):
+    """The ``ref_idiom=False`` statements of :func:`fit_predict` (north/June1st.py:265-277, :246) for RBF / Matern at sizes
+    where its n x n temporaries do not fit: K~ is formed in place in row blocks (same arithmetic per entry: squared distances
+    by direct differences, then the covariance function), factored in place (``scipy.linalg.cholesky(overwrite_a=True)``),
+    and only the scalars of the block are returned: fmean, fvar, sigma_f, sigma_n, nlml, A_tilde.  One n x n float64 array
+    at peak (8 GiB at n = 32768).  Checked against :func:`fit_predict` in tests/test_oracle_golden.py."""
+    from concurrent.futures import ThreadPoolExecutor
+    from scipy.linalg import cholesky
+    X = np.asarray(X, dtype=np.float64)
+    y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+    Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
+    n = len(y)
+    Kt = np.empty((n, n), order="F")                            # LAPACK's layout: potrf then works in place without a copy
+
+    def rows(i0):
+        i1 = min(n, i0 + row_block)
+        blk = cov_unit(kind, X[i0:i1], X, ell)                  # :265 (RBF / Matern in place of X Sigma X^T)
+        idx = np.arange(i0, i1)
+        blk[idx - i0, idx] += sn_tilde
+        Kt[i0:i1, :] = blk
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(rows, range(0, n, row_block)))
+    L_tilde = cholesky(Kt, lower=True, overwrite_a=True, check_finite=False)           # :265
+    A_tilde = solve_triangular(L_tilde, y, lower=True, check_finite=False)
+    A_tilde = solve_triangular(L_tilde, A_tilde, lower=True, trans="T", check_finite=False)   # :266
+    sf = float(y[:, 0] @ A_tilde[:, 0]) / n                                              # :267
+    sn = sf * sn_tilde                                                                   # :268
+    ks = cov_unit(kind, X, Xs, ell)                                                      # :272 in unit signal variance
+    v = solve_triangular(L_tilde, ks, lower=True, check_finite=False)                    # :274 (L = sqrt(sf) L~)
+    fmean = ks.T @ A_tilde[:, 0]                                                         # :276 (k* alpha = k~* A~)
+    fvar = sf * (1.0 + sn_tilde - np.sum(v * v, axis=0))                                 # :273, :277
+    nlml = 0.5 * n + np.log(L_tilde.diagonal()).sum() + 0.5 * n * np.log(sf) + 0.5 * n * np.log(2 * np.pi)   # :246, y^T alpha = n
+    return dict(fmean=fmean, fvar=fvar, sigma_f=sf, sigma_n=sn, nlml=nlml, A_tilde=A_tilde)
+
+
 # --------------------------------------------------------------------------------------------
 # a9: MLII   (north/June1st.py:235-257)
 # --------------------------------------------------------------------------------------------

@@ -233,10 +233,11 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const TI* __restrict__ W,
 
 // sum_i log L_ii over the diagonal entries [i0, i0 + icount) n (i < n) of a matrix given by its virtual origin (one rank's
 // block columns of a factor sharded by columns); accumulates into *out (one block)
-__global__ __launch_bounds__(256) void logdiag_window_kernel(const double* __restrict__ Mat, long ld, int n, int i0, int icount, double* __restrict__ out) {
+template <typename TI>
+__global__ __launch_bounds__(256) void logdiag_window_kernel(const TI* __restrict__ Mat, long ld, int n, int i0, int icount, double* __restrict__ out) {
   __shared__ double sh[4];
   double a = 0.0;
-  for (int i = i0 + threadIdx.x; i < i0 + icount && i < n; i += 256) a += log(Mat[(long)i * ld + i]);
+  for (int i = i0 + threadIdx.x; i < i0 + icount && i < n; i += 256) a += log((double)Mat[(long)i * ld + i]);
   a = block_reduce_sum(a, sh);
   if (threadIdx.x == 0) *out += a;
 }
@@ -318,10 +319,14 @@ template <> struct Vec16<double> { typedef d2 type; static constexpr int N = 2; 
 // contiguous in k: 16-byte loads, 1 KiB per wave-instruction).  kmode 0: k in [0, K);  1: k in [0, j] (rows of a lower-
 // triangular block);  2: k in [j, K) (rows of an upper-triangular block).  Elements outside the range are SELECTED away,
 // never multiplied (the other triangle of an inverse block is uninitialised memory).
+// Zadd (may be null; same leading dimension as Zin): the product is taken with Zin + Zadd (the sharded forward solve's
+// right-hand side minus the contributions all-reduced over the ranks).  pm_pw > 0: Zout is PANEL-MAJOR [panel][TS_RHS][pm_pw]
+// (entry of global row g = j_off + j of right-hand side r at ((g / pm_pw) TS_RHS + r) pm_pw + g % pm_pw), the layout in which
+// one panel's piece of every right-hand side is one contiguous message.
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Mx, long ld, int nrows, int K, int kmode,
                                                      const T* __restrict__ Zin, long ldzin, T* __restrict__ Zout, long ldzout,
-                                                     int nrhs, int sub) {
+                                                     int nrhs, int sub, const T* __restrict__ Zadd = nullptr, int pm_pw = 0, int j_off = 0) {
   typedef typename Vec16<T>::type V;
   constexpr int NV = Vec16<T>::N;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -340,7 +345,12 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Mx, l
 #pragma unroll
     for (int r = 0; r < TS_RHS; ++r) {
       if (r < nrhs) {
-        const V z = *(const V*)(Zin + (long)r * ldzin + k);
+        V z = *(const V*)(Zin + (long)r * ldzin + k);
+        if (Zadd != nullptr) {
+          const V z2 = *(const V*)(Zadd + (long)r * ldzin + k);
+#pragma unroll
+          for (int e = 0; e < NV; ++e) z[e] += z2[e];
+        }
 #pragma unroll
         for (int e = 0; e < NV; ++e) {
           const bool in = (k + e >= klo) && (k + e < khi);
@@ -355,7 +365,8 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Mx, l
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     if (lane == 0 && r < nrhs) {
-      T* o = Zout + (long)r * ldzout + j;
+      const int g = j_off + j;
+      T* o = pm_pw > 0 ? Zout + ((long)(g / pm_pw) * TS_RHS + r) * pm_pw + g % pm_pw : Zout + (long)r * ldzout + j;
       *o = sub ? *o - v : v;
     }
   }
@@ -512,13 +523,14 @@ __global__ void detrend_kernel(const double* __restrict__ data, int P, int T, co
 template <int DREG>
 __global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __restrict__ X, int dp, int n, int nrhs,
                                                                const double* __restrict__ Xq, long ldq, double* __restrict__ part,
-                                                               long ldp, int jlen, KParams kp) {
+                                                               long ldp, int jlen, KParams kp, int i0 = 0, int i1 = -1) {
   __shared__ double Xj[64][DREG + 1];
   __shared__ double Q[4][64];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int iend = i1 < 0 ? n : i1;                    // rows [i0, iend): one rank's share of a residual sharded by rows
+  const int i = i0 + blockIdx.x * 256 + threadIdx.x;
   double xi[DREG];
 #pragma unroll
-  for (int p = 0; p < DREG; ++p) xi[p] = (i < n) ? X[(long)i * dp + p] : 0.0;
+  for (int p = 0; p < DREG; ++p) xi[p] = (i < iend) ? X[(long)i * dp + p] : 0.0;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   const int jbeg = blockIdx.y * jlen, jend = min(n, jbeg + jlen);
   for (int j0 = jbeg; j0 < jend; j0 += 64) {
@@ -543,7 +555,7 @@ __global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __r
       for (int r = 0; r < 4; ++r) acc[r] = fma(kv, Q[r][jj], acc[r]);
     }
   }
-  if (i >= n) return;
+  if (i >= iend) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[((long)blockIdx.y * 4 + r) * ldp + i] = acc[r];
 }
@@ -551,9 +563,9 @@ template <int DREG>
 __global__ __launch_bounds__(256) void krefine_finish_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
                                                              const double* __restrict__ y, int dp, int n, int nrhs,
                                                              const double* __restrict__ part, long ldp, int nchunk,
-                                                             double* __restrict__ Rout, long ldr, KParams kp) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+                                                             double* __restrict__ Rout, long ldr, KParams kp, int i0 = 0, int i1 = -1) {
+  const int i = i0 + blockIdx.x * 256 + threadIdx.x;
+  if (i >= (i1 < 0 ? n : i1)) return;
   for (int r = 0; r < nrhs; ++r) {
     double b;
     if (r == 0) {
@@ -637,6 +649,27 @@ __global__ __launch_bounds__(256) void cross_mean_kernel(const double* __restric
   }
   a = block_reduce_sum(a, sh);
   if (threadIdx.x == 0) out[blockIdx.x] = a;
+}
+
+// pivot info of one rank as a double for the MIN all-reduce over the ranks (0 = none -> a huge value)
+__global__ void info_to_double_kernel(const int* __restrict__ info, double* __restrict__ out) { out[0] = info[0] != 0 ? (double)info[0] : 1e18; }
+
+// ---- panel-major work vectors of the sharded triangular solves (sigp_dist_fit, fp32 engine) ------------------------------
+// dst [panel][TS_RHS][pw] (float) <- src [rows][lds] (double), zero beyond `cols_valid` and for right-hand sides >= rows
+__global__ void pm_from_rows_kernel(const double* __restrict__ src, long lds, float* __restrict__ dst, int rows, int n_pad, int cols_valid, int pw) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)TS_RHS * n_pad) return;
+  const int r = (int)(idx / n_pad), i = (int)(idx % n_pad);
+  dst[((long)(i / pw) * TS_RHS + r) * pw + i % pw] = (r < rows && i < cols_valid) ? (float)src[(long)r * lds + i] : 0.0f;
+}
+// Xacc [rows][ldx] (double) (+)= src panel-major (float)
+__global__ void pm_to_rows_kernel(const float* __restrict__ src, double* __restrict__ Xacc, long ldx, int rows, int n_pad, int pw, int accumulate) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)rows * n_pad) return;
+  const int r = (int)(idx / n_pad), i = (int)(idx % n_pad);
+  const double v = (double)src[((long)(i / pw) * TS_RHS + r) * pw + i % pw];
+  double* o = Xacc + (long)r * ldx + i;
+  *o = accumulate ? *o + v : v;
 }
 
 }  // namespace sigp

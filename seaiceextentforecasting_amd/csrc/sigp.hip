@@ -16,6 +16,8 @@
 #include <vector>
 
 #include "../../include/sigp.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: the library is bound at run time (dlopen), see sigp_dist.inc
 #include "gemm_mfma.hpp"
 #include "kernels_misc.hpp"
 #include "potrf_diag.hpp"
@@ -105,17 +107,36 @@ struct sigp_handle {
   double* sm_out = nullptr; long cap_sm_out = 0;   // [nprob][4 + 2*mstride]
   int sm_ch = 32, sm_mmax = 0, sm_nmax = 0; long sm_lds = 0;
   int opt_small_nt64 = 0;                     // measurement switch: one wavefront per fit at orders <= 64
-  // owner-only sharding of one large fit (sigp_dist_local_*): this rank's block columns only
+  // one large fit sharded over the GPUs of a node (sigp_dist_fit): this rank's block columns only
   struct DistLocal {
     bool on = false;
     int W = 0, world = 1, rank = 0, P = 0;     // panel width in 128-blocks, ranks, number of panels
     std::vector<long> lcol;                    // per panel: first local column (elements), -1 = not this rank's
     long ncol = 0;                             // local columns = row stride of mat
-    double* mat = nullptr; long cap = 0;       // [(n_pad + 128)][ncol]: own panels side by side, ride rows at the bottom
-    double* dinv = nullptr; long cap_dinv = 0; // [T][128][128] inverse diagonal blocks (own blocks filled)
-    hipEvent_t ev_buf[2] = {nullptr, nullptr}; // last update that read receive buffer k
-    bool ev_set[2] = {false, false};
+    void* mat = nullptr; size_t cap = 0;       // [(n_pad + 128)][ncol] (fp64 or fp32): own panels side by side, ride rows at the bottom; cap in bytes
+    void* dinv = nullptr; size_t cap_dinv = 0; // [T][128][128] inverse diagonal blocks (own blocks filled); bytes
   } dl;
+  // the communicator of the sharded fit: the library's own RCCL communicator (sigp_dist_init), or a caller-supplied transport
+  struct DistComm {
+    int nranks = 1, rank = 0;
+    int kind = 0;                              // 0 = none (one rank), 1 = library RCCL communicator, 2 = caller transport (sigp_dist_init_transport)
+    void* comm = nullptr;                      // ncclComm_t
+    sigp_transport tr{};
+    hipStream_t s_comm = nullptr;              // the panel broadcasts run here, beside the update and panel streams
+    void* hstage = nullptr; size_t cap_hstage = 0;   // pinned staging buffer of a host-pointer transport
+    void* pbuf[2] = {nullptr, nullptr}; size_t cap_pbuf = 0;   // two packed-panel buffers in rotation (device)
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_mark = nullptr;
+    std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
+    // sharded triangular solves of the fp32 refinement: inverses of the own panels' diagonal blocks, panel-major work vectors
+    float* Uinv = nullptr; float* Vinv = nullptr; size_t cap_inv = 0;        // [own panel][PW][PW] each (upper: L_pp^-T, lower: L_pp^-1)
+    float* invP = nullptr; size_t cap_invP = 0;                              // scratch of one inversion
+    float* ft = nullptr; float* fx = nullptr; float* fr = nullptr; float* fc = nullptr; size_t cap_vec = 0; size_t cap_ft = 0;
+    double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
+    // statistics of the last sharded fit (sigp_get_stat "dist_*")
+    double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
+    double st_collectives = 0;
+  } dc;
+  int opt_dist_stats = 0;                      // time the broadcasts and the update stream's waits for them with HIP events
   int opt_owner_only = 0;                      // sigp_set_train does not allocate the full n x n slot matrix
   // state
   int kernel_id = -1;
@@ -136,7 +157,6 @@ struct sigp_handle {
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
-  int opt_dist_async = 0;    // sigp_dist_update / _unpack return without a host sync (caller uses sigp_dist_sync): look-ahead
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
   int opt_n64_tiles = 0;     // trailing updates on 128 x 64 workgroup tiles, 3 workgroups per CU (syrk_n64_kernel): bit 0 fp64, bit 1 fp32
   int opt_wide_tiles = 0;    // trailing updates on 128 x 256 workgroup tiles (syrk_wide_kernel): bit 0 fp64, bit 1 fp32
@@ -189,6 +209,8 @@ int fail(sigp_handle* h, int code, const char* fmt, ...) {
   } while (0)
 
 long round_up(long a, long b) { return (a + b - 1) / b * b; }
+
+void dist_release(sigp_handle* h);   // sigp_shard.inc
 
 int ensure(sigp_handle* h, double** p, long* cap, long need) {
   if (*cap >= need) return SIGP_OK;
@@ -987,7 +1009,9 @@ static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
 // (what the block triangular solves of the fp32 refinement use).  P is scratch of the same shape as U.
 // Blocks of U below its block diagonal are never written NOR read (the products skip them through GemmArgsT::ktri).
 template <typename Real>
-int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* dinvp, Real* U, Real* P, long ld, int T, int span) {
+int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const Real* dinvp, Real* U, Real* P, long ld, int T, int span) {
+  // Lm has its own leading dimension ldl (a rank's block columns of a sharded factor: the diagonal block of one of its panels
+  // sits in storage whose row stride is its column count); U and P share ld
   int rc;
   hipLaunchKernelGGL(transpose_blocks_kernel<Real>, dim3(T), dim3(256), 0, st, dinvp, U, ld);
   HIPCHK(h, hipGetLastError());
@@ -1001,9 +1025,10 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* din
       const int b0 = pass == 0 ? 0 : tail_left;
       const int rs = pass == 0 ? sblk : tail_r;                       // blocks in the right part
       const long o = (long)b0 * NB * (ld + 1), pairStride = (long)2 * sblk * NB * (ld + 1);
+      const long oL = (long)b0 * NB * (ldl + 1), pairStrideL = (long)2 * sblk * NB * (ldl + 1);
       GemmArgsT<Real> g1{};                                           // P = U11 L21^T
       g1.A = U + o; g1.lda = ld; g1.sA = pairStride;
-      g1.B = Lm + o + (long)sblk * NB * ld; g1.ldb = ld; g1.sB = pairStride;
+      g1.B = Lm + oL + (long)sblk * NB * ldl; g1.ldb = ldl; g1.sB = pairStrideL;
       g1.C = P + o + (long)sblk * NB; g1.ldc = ld; g1.sC = pairStride;
       g1.batch = nb2; g1.K = sblk * NB; g1.r0 = 0; g1.r1 = sblk; g1.c0 = 0; g1.c1 = rs; g1.lower = 0; g1.ktri = 1;
       if ((rc = launch_syrk128_t<Real, true>(h, st, g1))) return rc;
@@ -1025,7 +1050,18 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, const Real* din
 // =====================================================================================================
 extern "C" {
 
-int sigp_version(void) { return 200; }   // 2.0: + sigp_small_*, sigp_dist_local_*, sigp_corr_tau, sigp_area_sums, sigp_detrend, sigp_get_stat
+int sigp_version(void) { return 300; }   // 3.0: the sharded fit inside the library (sigp_dist_init / _fit), sigp_runtime_info, sigp_nlml_grad_batch
+
+// which HIP runtime serves this process (a process that also loads PyTorch-ROCm has two on disk; the first one mapped wins)
+int sigp_runtime_info(char* buf, int64_t len) {
+  if (!buf || len < 1) return SIGP_BAD_ARG;
+  int ver = 0;
+  const hipError_t e = hipRuntimeGetVersion(&ver);
+  Dl_info di{};
+  const char* path = (dladdr((void*)&hipRuntimeGetVersion, &di) && di.dli_fname) ? di.dli_fname : "?";
+  snprintf(buf, (size_t)len, "HIP runtime %d (%s) from %s", ver, e == hipSuccess ? "ok" : hipGetErrorString(e), path);
+  return SIGP_OK;
+}
 
 int sigp_create(sigp_handle** out, int device_id, int dtype) {
   if (!out) return SIGP_BAD_ARG;
@@ -1051,9 +1087,7 @@ int sigp_destroy(sigp_handle* h) {
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
   double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->rpart, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
-  if (h->dl.mat) (void)hipFree(h->dl.mat);
-  if (h->dl.dinv) (void)hipFree(h->dl.dinv);
-  for (auto e : h->dl.ev_buf) if (e) (void)hipEventDestroy(e);
+  dist_release(h);
   if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
   if (h->sm_probs) (void)hipFree(h->sm_probs);
   if (h->pred_kps) (void)hipFree(h->pred_kps);
@@ -1099,7 +1133,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "small_nt64")) { h->opt_small_nt64 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
-  if (!strcmp(name, "dist_async")) { h->opt_dist_async = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "dist_stats")) { h->opt_dist_stats = value != 0; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) {   // the generic 128-tile kernel spills 12 B/lane to scratch: never beside a second stream
@@ -1803,7 +1837,7 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
   // U = L~^-T (upper triangular, row-major in gU); P parks in gK
   {
     ProfScope ps(h, st, SIGP_KC_MLII, (double)n_pad * n_pad * n_pad / 3, 0.0);
-    if ((rc = trtri_levels<double>(h, st, s.mat, s.dinv, h->gU, h->gK, ld, T, T))) return rc;
+    if ((rc = trtri_levels<double>(h, st, s.mat, ld, s.dinv, h->gU, h->gK, ld, T, T))) return rc;
   }
   // K~^-1 = U U^T on the lower 128-tiles (LDS-DMA kernel; rows of U are zero left of their diagonal block, so tile (i, j)
   // sums k from 128 i: n^3/3 flops)
@@ -1854,7 +1888,15 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
 
 #include "sigp_callers.inc"   // sigp_small_*, sigp_corr_tau, sigp_area_sums, sigp_detrend
 
-#include "sigp_dist.inc"      // sigp_dist_*, sigp_dist_local_*
+}  // extern "C"
+
+namespace {
+#include "sigp_shard.inc"     // the sharded fit: transports, panel loop, sharded solves (templates: C++ linkage)
+}  // namespace
+
+extern "C" {
+
+#include "sigp_dist.inc"      // sigp_dist_*: the C ABI of the sharded fit
 
 int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   if (!h || !name || !value) return SIGP_BAD_ARG;
@@ -1863,8 +1905,22 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
     double b = 0;
     for (const auto& s : h->slots) if (s.mat) b += (double)s.capB * (double)(s.cap_npad + RIDE) * (double)s.cap_npad * sizeof(double);
     if (h->fmat) b += (double)std::max(1, h->cap_f_G) * (double)(h->cap_f_npad + RIDE) * (double)h->cap_f_npad * sizeof(float);
-    if (h->dl.mat) b += (double)h->dl.cap * sizeof(double);
+    if (h->dl.mat) b += (double)h->dl.cap;
     *value = b;
+    return SIGP_OK;
+  }
+  const struct { const char* nm; const double* v; } ds[] = {
+      {"dist_fit_ms", &h->dc.st_fit_ms}, {"dist_factor_ms", &h->dc.st_factor_ms}, {"dist_bcast_bytes", &h->dc.st_bcast_bytes}, {"dist_comm_ms", &h->dc.st_comm_ms},
+      {"dist_stall_ms", &h->dc.st_stall_ms}, {"dist_solve_ms", &h->dc.st_solve_ms}, {"dist_collectives", &h->dc.st_collectives}};
+  for (const auto& e : ds)
+    if (!strcmp(name, e.nm)) { *value = *e.v; return SIGP_OK; }
+  if (!strcmp(name, "dist_comm_ranks")) {        // what the communicator itself reports (ncclCommCount); 0 = no RCCL communicator on this handle
+    *value = 0;
+    if (h->dc.kind == 1 && h->dc.comm) {
+      RcclApi* api = rccl_api(nullptr);
+      int cnt = 0;
+      if (api && api->CommCount && api->CommCount((ncclComm_t)h->dc.comm, &cnt) == ncclSuccess) *value = cnt;
+    }
     return SIGP_OK;
   }
   return fail(h, SIGP_BAD_ARG, "get_stat: unknown name %s", name);

@@ -1,7 +1,7 @@
-"""Multi-GPU sharding of independent fits: the retrospective (year x grid-point) list is dealt
-round-robin over ranks, every rank factorises its share on its own GPU with no data-path collective, and the
-few floats per fit (sigma_f, nlml, info, mean, var) are all-gathered at the end over torch.distributed
-(backend "nccl" = RCCL on the GPU box, "gloo" in the CPU tests)."""
+"""Multi-GPU.  Independent fits: the retrospective (year x grid-point) list is dealt round-robin over
+ranks, every rank factorises its share on its own GPU with no data-path collective, and the few floats per fit
+(sigma_f, nlml, info, mean, var) are all-gathered at the end over torch.distributed (backend "nccl" = RCCL on the GPU
+box, "gloo" in the CPU tests).  One large fit: ``DistributedGPR`` over the library's own sharded fit (sigp_dist_*)."""
 import ctypes as C
 
 import numpy as np
@@ -65,40 +65,155 @@ def fit_batch_sharded(engine, X, y, Xs, ell, sn_tilde, rank, world, dist=None):
     return gather_results(r, F, rank, world, dist)
 
 
+def tcp_exchange_id(rank, world, addr="127.0.0.1", port=29555, make_id=None, timeout=120.0):
+    """Torch-free rendezvous for the 128-byte ncclUniqueId of ``sigp_dist_init``: rank 0 creates it (``make_id()``) and
+    serves it on (addr, port); every other rank connects and reads it.  Any other channel (MPI, a file, torch.distributed's
+    store) does as well -- the library only needs the same 128 bytes on every rank."""
+    import socket
+    import time
+    if rank == 0:
+        uid = make_id()
+        with socket.socket() as srv:
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            srv.settimeout(timeout)
+            for _ in range(world - 1):
+                c, _a = srv.accept()
+                with c:
+                    c.sendall(uid)
+        return uid
+    t0 = time.time()
+    while True:
+        try:
+            with socket.create_connection((addr, port), timeout=timeout) as c:
+                buf = b""
+                while len(buf) < 128:
+                    chunk = c.recv(128 - len(buf))
+                    if not chunk:
+                        raise ConnectionError("rendezvous: short read")
+                    buf += chunk
+                return buf
+        except (ConnectionRefusedError, ConnectionError):
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.05)
+
+
 class DistributedGPR:
-    """One large fit sharded over the GPUs of a node (BASELINE configs[3]): 1-D block-cyclic ownership
-    of outer panels (``outer_blocks`` x 128 columns).  Per panel: the owner factors it (diagonal blocks, panel
-    solve, panel-internal updates), the factored panel -- rows below it, the ride-along rows and the inverse
-    diagonal blocks -- is broadcast (``torch.distributed``: RCCL over xGMI with backend "nccl"), and every rank
-    applies the rank-K update to the panels it owns.  After the last panel every rank holds the whole factor and
-    the solved ride rows, so sigma_f / nlML / predictions are formed locally with no further collective.
+    """One large fit sharded over the GPUs of a node (BASELINE configs[3] fp64, configs[4] fp32 + fp64 refinement):
+    a thin wrapper over the library's own sharded fit (include/sigp.h: ``sigp_dist_init`` / ``sigp_dist_fit``) -- 1-D
+    block-cyclic ownership of outer panels (``outer_blocks`` x 128 columns), owner-only storage (per-rank matrix bytes ~
+    1/world), the block-row panel broadcast on the library's RCCL communicator with look-ahead, stream-ordered with events
+    (no host synchronisation per panel).  ``dtype="f32"``: the fp32 factor sharded the same way, triangular solves on the
+    distributed factor and the fp64 refinement residual sharded by rows.
 
-    ``dtype="f32"`` shards the fp32 factorisation of the mixed-precision engine the same way (panels travel as fp32);
-    the fp64 iterative refinement then runs replicated on every rank against its complete copy of the factor.
+    ``dist`` selects how the ranks find each other and what moves the panels:
 
-    Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277)."""
+    * ``None`` with ``world == 1``: nothing to move.
+    * an initialised ``torch.distributed`` with backend "nccl": the LIBRARY's RCCL communicator (one device per rank); torch only
+      carries the 128-byte unique id to the other ranks.
+    * an initialised ``torch.distributed`` with another backend (gloo): a host-pointer transport (``sigp_dist_init_transport``) --
+      the library stages panels through pinned memory and calls back into ``dist.broadcast`` / ``dist.all_reduce``.  This is
+      how several ranks rehearse on ONE GPU (RCCL needs a device per rank); same panel loop, same arithmetic.
+    * a callable ``exchange(uid_or_None) -> uid``: the library's RCCL communicator with any other rendezvous, e.g.
+      ``lambda mk: tcp_exchange_id(rank, world, port=..., make_id=mk)`` (no torch in the process).
 
-    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=4, lookahead=True, dtype="f64", owner_only=False):
+    Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277); the factor stays spread over
+    the ranks, so predictions exist for the points passed to ``fit(Xs=...)`` (they ride along the factorisation)."""
+
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=8, lookahead=True, dtype="f64", owner_only=True, stats=False, force_rccl=False):
         from .gpr import GPR
-        import torch
-        self._torch = torch
         self.rank, self.world, self.dist = int(rank), int(world), dist
         self.W = int(outer_blocks)
         self.lookahead = bool(lookahead)
-        self.dtype = dtype                     # "f32": fp32 factor sharded the same way, fp64 refinement replicated on every rank (configs[4])
-        # owner_only: a rank allocates, builds and updates only the block columns of its own panels (per-rank matrix bytes
-        # ~ 1/world; received panels are applied straight out of the receive buffer; ride-row reductions are all-reduced).
-        # The factor then stays spread over the ranks: predictions exist for the ride-along points only.
-        self.owner_only = bool(owner_only)
-        if self.owner_only and dtype != "f64":
-            raise ValueError("owner_only sharding is the fp64 engine's (the fp32 refinement needs the whole factor on every rank)")
+        self.dtype = dtype
+        self.owner_only = True                 # storage is always owner-only now (the replicated form of rounds 1-2 is gone)
         self.gp = GPR(kernel=kernel, device=device, dtype=dtype)
-        if self.owner_only:
-            self.gp.set_option("owner_only", 1)
+        self.gp.set_option("owner_only", 1)
+        if stats:
+            self.gp.set_option("dist_stats", 1)
         self.device = device
-        self._bufs = [None, None]
+        self.transport = "none"
+        self._force_rccl = bool(force_rccl)    # world == 1 only: open a one-rank RCCL communicator anyway (exercises the RCCL path on one GPU)
+        self._cb = None
+        self._own_ride = None
+        self._init_transport()
+
+    # ---- transports ------------------------------------------------------------------------------------------------
+    def _init_transport(self):
+        from . import _lib as L
+        gp, lib = self.gp, self.gp._lib
+        if self.world == 1:
+            if self._force_rccl:
+                self._rccl_init(self._make_id())
+            else:
+                gp._check(lib.sigp_dist_init(gp._h, 1, 0, None), "dist_init")
+            return
+        dist = self.dist
+        if dist is None:
+            raise ValueError("DistributedGPR: world > 1 needs `dist` (torch.distributed, or a callable that exchanges the unique id)")
+        if callable(dist) and not hasattr(dist, "broadcast"):
+            uid = dist(self._make_id if self.rank == 0 else None)
+            self._rccl_init(uid)
+            return
+        backend = dist.get_backend()
+        if backend == "nccl":
+            import torch
+            t = torch.zeros(128, dtype=torch.uint8, device="cuda:%d" % self.device)
+            if self.rank == 0:
+                t.copy_(torch.frombuffer(bytearray(self._make_id()), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            self._rccl_init(bytes(t.cpu().numpy().tobytes()))
+            return
+        self._host_transport(dist)
+
+    def _make_id(self):
+        buf = C.create_string_buffer(128)
+        rc = self.gp._lib.sigp_dist_unique_id(buf)
+        if rc != 0:
+            from . import _lib as L
+            raise L.SigpError("sigp_dist_unique_id failed (rc=%d): librccl could not be bound" % rc)
+        return buf.raw
+
+    def _rccl_init(self, uid):
+        gp = self.gp
+        buf = C.create_string_buffer(bytes(uid), 128)
+        gp._check(gp._lib.sigp_dist_init(gp._h, self.world, self.rank, buf), "dist_init")
+        self.transport = "rccl"
+
+    def _host_transport(self, dist):
+        import torch
+        from . import _lib as L
+
+        def as_tensor(buf, count, np_dtype):
+            arr = np.ctypeslib.as_array((C.c_uint8 * (count * np.dtype(np_dtype).itemsize)).from_address(buf)).view(np_dtype)
+            return torch.from_numpy(arr)
+
+        def bcast(ctx, buf, nbytes, root, stream):
+            try:
+                dist.broadcast(as_tensor(buf, int(nbytes), np.uint8), src=int(root))
+                return 0
+            except Exception:            # noqa: BLE001 -- an exception must not unwind through the C frames
+                return 1
+
+        def allreduce(ctx, buf, count, is_f32, op, stream):
+            try:
+                t = as_tensor(buf, int(count), np.float32 if is_f32 else np.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
+                return 0
+            except Exception:            # noqa: BLE001
+                return 1
+
+        self._cb = (L.BCAST_FN(bcast), L.ALLREDUCE_FN(allreduce))
+        self._tr = L.Transport(None, 0, self._cb[0], self._cb[1])
+        gp = self.gp
+        gp._check(gp._lib.sigp_dist_init_transport(gp._h, self.world, self.rank, C.byref(self._tr)), "dist_init_transport")
+        self.transport = "host"
 
     def close(self):
+        if getattr(self, "gp", None) is not None and getattr(self.gp, "_h", None):
+            self.gp._lib.sigp_dist_shutdown(self.gp._h)
         self.gp.close()
 
     def __enter__(self):
@@ -111,224 +226,61 @@ class DistributedGPR:
         return panel_index % self.world
 
     def fit(self, X, y, ell, sn_tilde, M=None, Xs=None):
-        """With ``lookahead`` (default) the owner of panel p+1 updates that panel's columns first, factors it and
-        starts its broadcast while every rank is still applying panel p to the rest of its columns, so the xGMI
-        transfer and the owner's latency chain hide behind the trailing update.  Without it the steps
-        run strictly one after the other.  Both orders do the same arithmetic: results are bit-identical."""
-        if self.owner_only:
-            return self._fit_owner_only(X, y, ell, sn_tilde, M, Xs)
+        """One call into ``sigp_dist_fit``: build of the own block columns, the panel loop with its broadcasts, the reductions
+        (all-reduced), and for the fp32 engine the sharded solves + refinement.  Results are identical on every rank; with and
+        without ``lookahead`` the arithmetic is the same (bit-identical results)."""
         from . import _lib as L
         from .gpr import LinAlgError
-        torch, gp, lib = self._torch, self.gp, self.gp._lib
+        gp, lib = self.gp, self.gp._lib
         gp.set_data(X, y, M=M, Xs=Xs)          # X, y replicated on every rank (n*d*8 bytes)
-        gp.build(ell, sn_tilde)                # every rank builds K~; it only ever updates the panels it owns
-        gp._check(lib.sigp_dist_begin(gp._h), "dist_begin")
-        gp.set_option("dist_async", 1 if self.lookahead else 0)
-        T = int(lib.sigp_num_blocks(gp._h))
-        panels = [(J, min(self.W, T - J)) for J in range(0, T, self.W)]
-        P = len(panels)
-        nelem = [int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels]
-        nmax = max(nelem) + 1
-        for k in range(2):                     # two broadcast buffers: panel p+1 is received while panel p is in use
-            if self._bufs[k] is None or self._bufs[k].numel() < nmax:
-                self._bufs[k] = torch.empty(nmax, dtype=torch.float64 if self.dtype == "f64" else torch.float32, device="cuda:%d" % self.device)
+        if Xs is not None and gp._ride is None:
+            raise ValueError("sharded fit: at most %d ride-along test points" % (L.MAX_RIDE if self.dtype == "f64" else 3))
+        return self.refit(ell, sn_tilde)
 
-        def view(p):
-            return self._bufs[p % 2][:nelem[p] + 1]
-
-        def factor_and_pack(p):                # owner: panel p is up to date -> factor, pack [panel | dinv | info]
-            J, Wc = panels[p]
-            pinfo = C.c_int64(0)
-            gp._check(lib.sigp_dist_panel_factor(gp._h, J, Wc, C.byref(pinfo)), "dist_panel_factor")
-            gp._check(lib.sigp_dist_sync(gp._h, 1), "dist_sync")          # the buffer's previous panel is unpacked
-            gp._check(lib.sigp_dist_panel_pack(gp._h, J, Wc, C.c_void_p(view(p).data_ptr())), "dist_panel_pack")
-            view(p)[nelem[p]] = float(pinfo.value)
-
-        def start_bcast(p):                    # the block-row panel broadcast (RCCL over xGMI with backend "nccl")
-            if self.world == 1:
-                return None
-            return self.dist.broadcast(view(p), src=self.owner(p), async_op=True)
-
-        def wait_bcast(work):
-            if work is not None:
-                work.wait()
-            torch.cuda.synchronize(self.device) if not self.lookahead else torch.cuda.current_stream(self.device).synchronize()
-
-        def update(p, q):                      # columns of panel q -= (panel p)(panel p)^T rows
-            J, Wc = panels[p]
-            Jq, Wq = panels[q]
-            c0 = Jq - (J + Wc)
-            gp._check(lib.sigp_dist_update(gp._h, J, Wc, c0, c0 + Wq), "dist_update")
-
-        info = 0
-        try:
-            if self.rank == self.owner(0):
-                factor_and_pack(0)
-            work = start_bcast(0)
-            for p in range(P):
-                J, Wc = panels[p]
-                wait_bcast(work)
-                work = None
-                info = int(view(p)[nelem[p]].item())
-                if info != 0:
-                    break
-                if self.rank != self.owner(p):
-                    gp._check(lib.sigp_dist_panel_unpack(gp._h, J, Wc, C.c_void_p(view(p).data_ptr())), "dist_panel_unpack")
-                mine = [q for q in range(p + 1, P) if self.owner(q) == self.rank]
-                nxt = p + 1
-                if self.lookahead and nxt < P:
-                    if self.owner(nxt) == self.rank:
-                        update(p, nxt)                         # the next panel's own columns first ...
-                        gp._check(lib.sigp_dist_mark(gp._h), "dist_mark")
-                        mine.remove(nxt)
-                        for q in mine:                         # ... the rest of this rank's updates run on the update stream
-                            update(p, q)
-                        mine = []
-                        factor_and_pack(nxt)                   # ... while the panel stream factors and packs panel p+1
-                    else:
-                        gp._check(lib.sigp_dist_sync(gp._h, 1), "dist_sync")   # buffer (p+1)%2 free: panel p-1 unpacked
-                    work = start_bcast(nxt)
-                for q in mine:
-                    update(p, q)
-                if not self.lookahead and nxt < P:
-                    if self.owner(nxt) == self.rank:
-                        factor_and_pack(nxt)
-                    work = start_bcast(nxt)
-            if work is not None:                   # non-SPD exit with a broadcast in flight: complete the collective
-                wait_bcast(work)
-        finally:
-            gp._check(lib.sigp_dist_sync(gp._h, 0), "dist_sync")
-            gp.set_option("dist_async", 0)
-        out = np.zeros(4)
-        m = 0 if gp._ride is None else gp._ride.shape[0]
-        mean, var = np.zeros(max(m, 1)), np.zeros(max(m, 1))
-        rc = lib.sigp_dist_finish(gp._h, info, L.ptr(out), L.ptr(mean), L.ptr(var))
-        gp.info_ = info
-        if rc == L.NOT_SPD:
-            raise LinAlgError("Matrix is not positive definite (pivot %d)" % info, info)
-        gp._check(rc, "dist_finish")
-        gp.sigma_f_, gp.nlml_, gp.sigma_n_ = float(out[0]), float(out[1]), float(out[3])
-        gp._ride_mean, gp._ride_var = mean[:m].copy(), var[:m].copy()
-        gp._fitted = True
-        self.sigma_f_, self.nlml_, self.sigma_n_ = gp.sigma_f_, gp.nlml_, gp.sigma_n_
-        return self
-
-    def _fit_owner_only(self, X, y, ell, sn_tilde, M, Xs):
-        """The same panel loop on owner-only storage (include/sigp.h: sigp_dist_local_*)."""
+    def refit(self, ell, sn_tilde):
+        """The sharded fit again on the staged data with new hyper-parameters (every rank calls it)."""
         from . import _lib as L
         from .gpr import LinAlgError
-        torch, gp, lib = self._torch, self.gp, self.gp._lib
-        if Xs is None:
-            raise ValueError("owner_only: pass the test points to fit(Xs=...) -- they ride along the factorisation; the factor itself stays sharded")
-        gp.set_data(X, y, M=M, Xs=Xs)
-        if gp._ride is None:
-            raise ValueError("owner_only: at most %d ride-along test points" % L.MAX_RIDE)
-        gp._check(lib.sigp_dist_local_begin(gp._h, self.W, self.world, self.rank), "dist_local_begin")
+        gp, lib = self.gp, self.gp._lib
+        if not gp._has_data:
+            raise RuntimeError("refit: no data staged; call fit() first")
         Sig = None
         if gp.kernel == "netdiffusion":
             Sig = L.f64(gp._sigma(float(ell)), 2)
-        gp._check(lib.sigp_dist_local_build(gp._h, gp._kid, float(ell), float(sn_tilde), L.ptr(Sig), 0 if Sig is None else Sig.shape[1]), "dist_local_build")
-        gp.set_option("dist_async", 1 if self.lookahead else 0)
-        T = int(lib.sigp_num_blocks(gp._h))
-        panels = [(J, min(self.W, T - J)) for J in range(0, T, self.W)]
-        P = len(panels)
-        nelem = [int(lib.sigp_dist_panel_elems(gp._h, J, Wc)) for J, Wc in panels]
-        nmax = max(nelem) + 1
-        for k in range(2):
-            if self._bufs[k] is None or self._bufs[k].numel() < nmax:
-                self._bufs[k] = torch.empty(nmax, dtype=torch.float64, device="cuda:%d" % self.device)
-
-        def view(p):
-            return self._bufs[p % 2][:nelem[p] + 1]
-
-        def factor_and_pack(p):
-            pinfo = C.c_int64(0)
-            gp._check(lib.sigp_dist_local_buffer_wait(gp._h, p % 2), "dist_local_buffer_wait")    # updates with panel p-2 are done with the buffer
-            gp._check(lib.sigp_dist_local_factor(gp._h, p, C.c_void_p(view(p).data_ptr()), C.byref(pinfo)), "dist_local_factor")
-            view(p)[nelem[p]] = float(pinfo.value)
-
-        def start_bcast(p):
-            if self.world == 1:
-                return None
-            if self.rank != self.owner(p):
-                gp._check(lib.sigp_dist_local_buffer_wait(gp._h, p % 2), "dist_local_buffer_wait")
-            return self.dist.broadcast(view(p), src=self.owner(p), async_op=True)
-
-        def wait_bcast(work):
-            if work is not None:
-                work.wait()
-            torch.cuda.synchronize(self.device) if not self.lookahead else torch.cuda.current_stream(self.device).synchronize()
-
-        def update(p, q):
-            gp._check(lib.sigp_dist_local_update(gp._h, p, C.c_void_p(view(p).data_ptr()), q, p % 2), "dist_local_update")
-
-        info = 0
-        try:
-            if self.rank == self.owner(0):
-                factor_and_pack(0)
-            work = start_bcast(0)
-            for p in range(P):
-                wait_bcast(work)
-                work = None
-                info = int(view(p)[nelem[p]].item())
-                if info != 0:
-                    break
-                mine = [q for q in range(p + 1, P) if self.owner(q) == self.rank]
-                nxt = p + 1
-                if self.lookahead and nxt < P:
-                    if self.owner(nxt) == self.rank:
-                        update(p, nxt)                         # the next panel's own columns first ...
-                        gp._check(lib.sigp_dist_mark(gp._h), "dist_mark")
-                        mine.remove(nxt)
-                        for q in mine:
-                            update(p, q)
-                        mine = []
-                        factor_and_pack(nxt)                   # ... the panel stream factors and packs panel p+1 meanwhile
-                    work = start_bcast(nxt)
-                for q in mine:
-                    update(p, q)
-                if not self.lookahead and nxt < P:
-                    if self.owner(nxt) == self.rank:
-                        factor_and_pack(nxt)
-                    work = start_bcast(nxt)
-            if work is not None:
-                wait_bcast(work)
-        finally:
-            gp._check(lib.sigp_dist_sync(gp._h, 0), "dist_sync")
-            gp.set_option("dist_async", 0)
-        res = np.zeros(512)
-        gp._check(lib.sigp_dist_local_reduce(gp._h, L.ptr(res)), "dist_local_reduce")
-        if self.world > 1:                                      # the one exchange besides the panel broadcast: 512 doubles
-            t = torch.from_numpy(res)
-            if self.dist.get_backend() == "nccl":
-                t = t.cuda(self.device)
-            self.dist.all_reduce(t)
-            res = t.cpu().numpy().copy()
         out = np.zeros(4)
-        m = gp._ride.shape[0]
+        m = 0 if gp._ride is None else gp._ride.shape[0]
         mean, var = np.zeros(max(m, 1)), np.zeros(max(m, 1))
-        rc = lib.sigp_dist_local_results(gp._h, L.ptr(res), info, L.ptr(out), L.ptr(mean), L.ptr(var))
-        gp.info_ = info
+        rc = lib.sigp_dist_fit(gp._h, gp._kid, float(ell), float(sn_tilde), L.ptr(Sig), 0 if Sig is None else Sig.shape[1], self.W,
+                               int(self.lookahead), L.ptr(out), L.ptr(mean), L.ptr(var))
+        gp.info_ = int(out[2]) if rc in (L.OK, L.NOT_SPD) else -1
         if rc == L.NOT_SPD:
-            raise LinAlgError("Matrix is not positive definite (pivot %d)" % info, info)
-        gp._check(rc, "dist_local_results")
+            raise LinAlgError("Matrix is not positive definite (pivot %d)" % gp.info_, gp.info_)
+        gp._check(rc, "dist_fit")
         gp.sigma_f_, gp.nlml_, gp.sigma_n_ = float(out[0]), float(out[1]), float(out[3])
         gp._ride_mean, gp._ride_var = mean[:m].copy(), var[:m].copy()
         gp._fitted = False
-        self._own_ride = (gp._ride.copy(), gp._ride_mean, gp._ride_var)
+        self._own_ride = (None if gp._ride is None else gp._ride.copy(), gp._ride_mean, gp._ride_var)
         self.sigma_f_, self.nlml_, self.sigma_n_ = gp.sigma_f_, gp.nlml_, gp.sigma_n_
         return self
 
     @property
     def matrix_bytes_(self):
-        """Device bytes this rank holds in matrix / factor buffers (owner_only: ~ 1/world of the replicated form)."""
+        """Device bytes this rank holds in matrix / factor buffers (~ 1/world of the single-GPU matrix)."""
         return self.gp.matrix_bytes_
 
+    @property
+    def refine_residual_(self):
+        return self.gp.refine_residual_
+
+    def stats(self):
+        """``dist_*`` statistics of the last fit (meaningful with ``stats=True``): ms and bytes on THIS rank."""
+        return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks")}
+
     def predict(self, Xs):
-        if self.owner_only:
-            ride, mu, var = self._own_ride
-            Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
-            if Xs.shape != ride.shape or not np.array_equal(Xs, ride):
-                raise RuntimeError("owner_only: the factor is spread over the ranks; predictions exist for the points passed to fit(Xs=...)")
-            return mu.copy(), var.copy()
-        return self.gp.predict(Xs)
+        if self._own_ride is None:
+            raise RuntimeError("predict: call fit() first")
+        ride, mu, var = self._own_ride
+        Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
+        if ride is None or Xs.shape != ride.shape or not np.array_equal(Xs, ride):
+            raise RuntimeError("sharded fit: the factor is spread over the ranks; predictions exist for the points passed to fit(Xs=...)")
+        return mu.copy(), var.copy()

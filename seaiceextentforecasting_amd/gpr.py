@@ -47,8 +47,8 @@ class GPR:
         h = C.c_void_p()
         rc = self._lib.sigp_create(C.byref(h), int(device), 0 if dtype == "f64" else 1)
         if rc != L.OK:
-            raise L.SigpError("sigp_create(device=%d) failed (rc=%d): no usable MI355X / HIP runtime; there is no CPU fallback"
-                              % (device, rc))
+            raise L.SigpError("sigp_create(device=%d) failed (rc=%d): no usable MI355X / HIP runtime [%s]; there is no CPU fallback"
+                              % (device, rc, L.runtime_info()))
         self._h = h
         self.device = device
         self._has_data = False
@@ -359,7 +359,11 @@ class GPR:
             X, y, Xs, M = [X], [y], [Xs], [M]
         B = len(X)
         Xs = [None] * B if Xs is None else list(Xs)
+        if M is not None and isinstance(M, np.ndarray) and M.ndim == 2 and B > 1:
+            raise ValueError("M must be None or a sequence of %d Laplacians (one per data set), not a single array" % B)
         M = [None] * B if M is None else list(M)
+        if len(M) != B or len(Xs) != B:
+            raise ValueError("X, Xs and M must have one entry per data set (%d)" % B)
         ell = np.atleast_1d(np.asarray(ell, dtype=np.float64)); sn = np.atleast_1d(np.asarray(sn_tilde, dtype=np.float64))
         F = len(ell)
         if len(sn) != F:
@@ -381,7 +385,10 @@ class GPR:
                 res[k][small] = r[k]
             res["mean"][small, :r["mean"].shape[1]] = r["mean"]
             res["var"][small, :r["var"].shape[1]] = r["var"]
-        for i in (i for i in range(F) if i not in set(small)):          # orders beyond one workgroup: the blocked engine, one fit at a time
+        small_set = set(small)
+        for i in range(F):                                                # orders beyond one workgroup: the blocked engine, one fit at a time
+            if i in small_set:
+                continue
             b = i % B
             try:
                 self.fit(X[b], y[b], ell[i], sn[i], M=M[b], Xs=Xs[b])

@@ -387,80 +387,6 @@ def test_full_size_properties_n8192_batch(S):
     assert np.array_equal(r2["mean"][:3], r2["mean"][6:9])                # same (data set, hyper-parameters) -> same bits
 
 
-_DIST_WORKER = r'''
-import os, sys
-sys.path.insert(0, %(root)r)
-import numpy as np
-import torch, torch.distributed as dist
-from oracle import gp_oracle as O
-import seaiceextentforecasting_amd as S
-rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")          # 2 ranks share the box's single GPU: gloo moves the panels (RCCL needs 2 devices)
-for kind, n, d, W in (("rbf", 1100, 8, 2), ("netdiffusion", 700, 12, 1), ("matern52", 515, 4, 3)):
-    X, y, Xs = O.synthetic_problem(n, d, 4242 + n, m=3)
-    ell, sn = (np.sqrt(d), 1e-2) if kind != "netdiffusion" else (0.05, 1e-2)
-    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
-    Ls = []
-    for la in (True, False):               # look-ahead (panel p+1 broadcast overlaps the updates with panel p) and strict order
-        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la) as dg:
-            dg.fit(X, y, ell, sn, Xs=Xs)
-            mu, var = dg.predict(Xs)
-            mu2, var2 = dg.predict(Xs[:2] + 0.1)
-            L, nl = dg.gp.L_tilde_, dg.nlml_
-            dg.fit(X, y * 2.0, ell, sn, Xs=Xs)          # a second fit on the same handle (buffer reuse)
-            mu3, _ = dg.predict(Xs)
-        ref2 = O.fit_predict(X, y, Xs[:2] + 0.1, ell, sn, kind=kind, M=ref["M"], ref_idiom=False)
-        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
-        assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank, la)
-        assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la)
-        assert rel(nl, ref["nlml"]) <= 1e-9 and rel(L, ref["L_tilde"]) <= 1e-11, (kind, rank, la)
-        assert rel(mu3, 2.0 * ref["fmean"]) <= 1e-8, (kind, rank, la)
-        Ls.append(L)
-    assert np.array_equal(Ls[0], Ls[1]), "look-ahead changed the factor"
-# configs[4] shape at test size: fp32 factor sharded over the ranks, fp64 refinement replicated
-X, y, Xs = O.synthetic_problem(900, 16, 515, m=2)
-ref = O.fit_predict(X, y, Xs, 4.0, 1e-1, kind="matern52", ref_idiom=False)
-rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
-for la in (True, False):
-    with S.DistributedGPR("matern52", rank, world, dist, device=0, outer_blocks=2, lookahead=la, dtype="f32") as dg:
-        dg.fit(X, y, 4.0, 1e-1, Xs=Xs)
-        mu, var = dg.predict(Xs)
-        assert rel(mu, ref["fmean"]) <= 1e-6 and rel(dg.sigma_f_, ref["sigma_f"]) <= 1e-6, (rank, la, rel(mu, ref["fmean"]))
-        assert rel(var, ref["fvar"]) <= 1e-3 and rel(dg.nlml_, ref["nlml"]) <= 1e-5, (rank, la)
-# non-SPD: every rank learns the failing pivot from the broadcast panel and raises like np.linalg.cholesky
-X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
-X[300:350] = X[100:150]
-for la in (True, False):
-    with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=2, lookahead=la) as dg:
-        try:
-            dg.fit(X, y, 2.0, 0.0, Xs=Xs)
-            raise SystemExit("expected LinAlgError")
-        except np.linalg.LinAlgError as e:
-            assert 300 < e.info <= 350, e.info
-        dg.fit(X, y, 2.0, 1e-2, Xs=Xs)                  # the handle stays usable
-        assert np.isfinite(dg.nlml_)
-dist.barrier(); dist.destroy_process_group()
-open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
-'''
-
-
-@pytest.mark.parametrize("world", [1, 2])
-def test_sharded_cholesky_panel_broadcast(tmp_path, world):
-    """BASELINE configs[3] path at test size: block-cyclic panels over `world` ranks with the panel broadcast
-    (gloo here, two processes on the one GPU; RCCL on a multi-GPU node) == oracle on every rank."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "worker.py"
-    script.write_text(_DIST_WORKER % dict(root=root, out=str(tmp_path)))
-    port = 29600 + (os.getpid() % 300) + world
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
-           "--master-port", str(port), str(script)]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=500)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    for r in range(world):
-        assert (tmp_path / ("ok_%d" % r)).exists()
-
-
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
 @pytest.mark.parametrize("n,d", [(300, 4), (1024, 8), (2049, 32)])
 def test_fp32_engine_with_fp64_refinement(S, kind, n, d):

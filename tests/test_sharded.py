@@ -1,0 +1,271 @@
+"""One large fit sharded over ranks, inside the library (include/sigp.h: sigp_dist_init / sigp_dist_init_transport /
+sigp_dist_fit; SURVEY 8e, BASELINE configs[3] and [4]).
+
+The GPU box has ONE GPU and RCCL needs a device per rank, so the multi-rank cases run the SAME panel loop over the
+host-pointer transport (gloo between processes that share the GPU); the RCCL transport itself is exercised with a one-rank
+communicator (here, torch-free, and in test_hip_round2.py::test_rccl_backend_world1 with torch loaded).  Tolerances: fp64
+predictions <= 1e-8, nlML / sigma_f <= 1e-9 against the oracle; fp32 + refinement: mean / sigma_f <= 1e-6, variance <= 1e-5,
+nlML <= 1e-5, refinement residual in (0, 1e-10].
+"""
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import gp_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---- CPU tier: host logic ---------------------------------------------------------------------------------------------
+def test_tcp_rendezvous_hands_the_same_id_to_every_rank():
+    from seaiceextentforecasting_amd.dist import tcp_exchange_id
+    port = 29300 + os.getpid() % 500
+    uid = bytes(range(128))
+    got = {}
+
+    def run(rank):
+        got[rank] = tcp_exchange_id(rank, 3, port=port, make_id=(lambda: uid) if rank == 0 else None, timeout=30)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == {0: uid, 1: uid, 2: uid}
+
+
+def test_transport_struct_matches_the_header():
+    """sigp_transport of include/sigp.h <-> _lib.Transport: four pointer-sized / int fields in the declared order."""
+    import ctypes as C
+    from seaiceextentforecasting_amd import _lib as L
+    names = [f[0] for f in L.Transport._fields_]
+    assert names == ["ctx", "device_buffers", "bcast", "allreduce"]
+    assert C.sizeof(L.Transport) == 4 * C.sizeof(C.c_void_p)          # int padded to pointer alignment
+    hdr = open(os.path.join(ROOT, "include", "sigp.h")).read()
+    body = hdr[hdr.index("typedef struct sigp_transport {"):hdr.index("} sigp_transport;")]
+    order = [body.index(k) for k in ("void* ctx;", "int device_buffers;", "(*bcast)", "(*allreduce)")]
+    assert order == sorted(order)
+
+
+def test_sharded_fit_rejects_bad_arguments_without_a_gpu():
+    from seaiceextentforecasting_amd import _lib as L
+    lib = L.load()
+    assert lib.sigp_dist_unique_id(None) == L.BAD_ARG
+    assert lib.sigp_dist_init(None, 2, 0, None) == L.BAD_ARG
+    assert lib.sigp_dist_init_transport(None, 2, 0, None) == L.BAD_ARG
+    assert lib.sigp_dist_fit(None, 1, 1.0, 0.1, None, 0, 8, 1, None, None, None) == L.BAD_ARG
+    assert lib.sigp_dist_shutdown(None) == L.BAD_ARG
+    assert "HIP runtime" in L.runtime_info()
+
+
+# ---- GPU tier -----------------------------------------------------------------------------------------------------------
+_WORKER = r'''
+import os, sys
+import torch, torch.distributed as dist          # torch BEFORE the library: two HIP runtimes on disk, the first one mapped serves both
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")          # ranks share the box's single GPU: the host-pointer transport moves the panels
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("matern52", 1100, 4, 3), ("rbf", 300, 3, 4), ("rbf", 1500, 6, 16)):
+    X, y, Xs = O.synthetic_problem(n, d, 4242 + n, m=3)
+    ell, sn = (np.sqrt(d), 1e-2) if kind != "netdiffusion" else (0.05, 1e-2)
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    with S.GPR(kernel=kind) as g1:           # the single-GPU engine on the same inputs
+        g1.fit(X, y, ell, sn, Xs=Xs)
+        one = (g1.predict(Xs), g1.nlml_, g1.matrix_bytes_)
+    bits = []
+    for la in (True, False):
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la, stats=True) as dg:
+            assert dg.transport == ("host" if world > 1 else "none")
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8, (kind, rank, la, rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
+            assert rel(dg.nlml_, ref["nlml"]) <= 1e-9 and rel(dg.sigma_f_, ref["sigma_f"]) <= 1e-9, (kind, rank, la)
+            assert rel(mu, one[0][0]) <= 1e-11 and rel(dg.nlml_, one[1]) <= 1e-12      # the single-GPU engine's numbers
+            bits.append((mu.copy(), var.copy(), dg.nlml_))
+            # per-rank matrix bytes ~ 1/world (block-cyclic shares differ by at most one panel)
+            T = -(-n // 128); P = -(-T // W)
+            mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
+            assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 8) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)
+            if world > 1 and T >= 4 * W:
+                assert dg.matrix_bytes_ <= 0.75 * one[2], (dg.matrix_bytes_, one[2])
+            st = dg.stats()
+            assert st["fit_ms"] > 0 and (world == 1 or st["bcast_bytes"] > 0), st
+            try:
+                dg.predict(Xs + 1.0)
+                raise SystemExit("expected RuntimeError")
+            except RuntimeError:
+                pass
+            dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
+            assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
+    assert np.array_equal(bits[0][0], bits[1][0]) and np.array_equal(bits[0][1], bits[1][1]) and bits[0][2] == bits[1][2], "look-ahead changed the bits"
+# configs[4] shape at test size: fp32 factor sharded, triangular solves on the distributed factor, residual sharded by rows
+for kind, n, d, W, m in (("matern52", 900, 16, 2, 2), ("rbf", 2049, 32, 3, 3), ("matern52", 1500, 8, 1, 0), ("rbf", 300, 4, 4, 1)):
+    X, y, Xs = O.synthetic_problem(n, d, 515 + n, m=max(m, 1))
+    Xs = Xs[:m] if m else None
+    ell, sn = np.sqrt(d), 1e-1
+    ref = O.fit_predict(X, y, Xs if m else X[:1], ell, sn, kind=kind, ref_idiom=False)
+    with S.GPR(kernel=kind, dtype="f32") as g1:
+        g1.fit(X, y, ell, sn, Xs=Xs)
+        one = (g1.predict(Xs) if m else None, g1.nlml_, g1.sigma_f_)
+    for la in (True, False):
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la, dtype="f32") as dg:
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            assert 0.0 < dg.refine_residual_ <= 1e-10, (kind, n, rank, la, dg.refine_residual_)
+            assert rel(dg.sigma_f_, ref["sigma_f"]) <= 1e-6 and rel(dg.nlml_, ref["nlml"]) <= 1e-5, (kind, n, rank, la, rel(dg.sigma_f_, ref["sigma_f"]))
+            assert rel(dg.sigma_f_, one[2]) <= 1e-9                                      # the refined fp64 solutions agree with the single-GPU fp32 engine's
+            if m:
+                mu, var = dg.predict(Xs)
+                assert rel(mu, ref["fmean"]) <= 1e-6 and rel(var, ref["fvar"]) <= 1e-5, (kind, n, rank, la, rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
+            T = -(-n // 128); P = -(-T // W)
+            mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
+            assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 4) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)   # fp32: half the bytes, ~ 1/world
+# non-SPD: every rank learns the first failing pivot from the MIN all-reduce and raises like np.linalg.cholesky
+X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
+X[300:350] = X[100:150]
+for dtype in ("f64", "f32"):
+    for la in (True, False):
+        with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=2, lookahead=la, dtype=dtype) as dg:
+            try:
+                dg.fit(X, y, 2.0, 0.0, Xs=Xs)
+                raise SystemExit("expected LinAlgError")
+            except np.linalg.LinAlgError as e:
+                assert 300 < e.info <= 350, e.info
+            dg.fit(X, y, 2.0, 1e-1, Xs=Xs)               # the handle stays usable
+            assert np.isfinite(dg.nlml_)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+'''
+
+
+def _torchrun(script, world, port, timeout):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(script)]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_sharded_fit_inside_the_library(tmp_path, world):
+    """sigp_dist_fit at test sizes, fp64 and fp32, world 1-3: == oracle on every rank, == the single-GPU engine, bit-identical
+    with and without look-ahead, per-rank matrix bytes ~ 1/world, non-SPD exit on every rank, handle reuse."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % dict(root=ROOT, out=str(tmp_path)))
+    p = _torchrun(script, world, 29700 + (os.getpid() % 150) + world, 560)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    for r in range(world):
+        assert (tmp_path / ("ok_%d" % r)).exists()
+
+
+_RCCL_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+assert "torch" not in sys.modules            # the library alone: /opt/rocm's HIP runtime and /opt/rocm's librccl, bound with dlopen
+from seaiceextentforecasting_amd import _lib as L
+assert "/opt/rocm" in L.runtime_info(), L.runtime_info()
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+X, y, Xs = O.synthetic_problem(1700, 8, 77, m=3)
+ref = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-2, kind="rbf", ref_idiom=False)
+for dtype, tol in (("f64", 1e-8), ("f32", 1e-6)):
+    for la in (True, False):
+        with S.DistributedGPR("rbf", 0, 1, None, device=0, outer_blocks=2, lookahead=la, dtype=dtype, force_rccl=True, stats=True) as dg:
+            assert dg.transport == "rccl"
+            dg.fit(X, y, np.sqrt(8.0), 1e-2 if dtype == "f64" else 1e-1, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            st = dg.stats()
+        if dtype == "f64":
+            assert rel(mu, ref["fmean"]) <= tol and rel(var, ref["fvar"]) <= tol and rel(dg.nlml_, ref["nlml"]) <= 1e-9
+        else:
+            r32 = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-1, kind="rbf", ref_idiom=False)
+            assert rel(mu, r32["fmean"]) <= tol and rel(var, r32["fvar"]) <= 1e-5 and 0 < dg.refine_residual_ <= 1e-10
+        assert st["collectives"] >= 7 + 2 and st["bcast_bytes"] > 0 and st["comm_ms"] > 0, st
+# the rendezvous channel that needs no torch
+from seaiceextentforecasting_amd.dist import tcp_exchange_id
+with S.DistributedGPR("rbf", 0, 1, None, device=0, force_rccl=True) as dg:
+    uid = tcp_exchange_id(0, 1, port=%(port)d, make_id=dg._make_id)
+    assert len(uid) == 128
+open(os.path.join(%(out)r, "ok_rccl"), "w").write("ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_library_rccl_communicator_without_torch(tmp_path):
+    """sigp_dist_unique_id / sigp_dist_init / sigp_dist_fit on the library's OWN RCCL communicator (one rank: every panel
+    broadcast and all-reduce is a real RCCL call on the library's streams), in a process that never imports torch."""
+    script = tmp_path / "worker.py"
+    script.write_text(_RCCL_WORKER % dict(root=ROOT, out=str(tmp_path), port=29200 + os.getpid() % 400))
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=380, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert (tmp_path / "ok_rccl").exists()
+
+
+_BIG_WORKER = r'''
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import numpy as np
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+z = np.load(%(ref)r)
+X, y, Xs = z["X"], z["y"], z["Xs"]
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=8, stats=True) as dg:
+    dg.fit(X, y, float(z["ell"]), float(z["sn"]), Xs=Xs)
+    mu, var = dg.predict(Xs)
+    assert rel(mu, z["fmean"]) <= 1e-8 and rel(var, z["fvar"]) <= 1e-8, (rank, rel(mu, z["fmean"]), rel(var, z["fvar"]))
+    assert rel(dg.nlml_, z["nlml"]) <= 1e-9 and rel(dg.sigma_f_, z["sigma_f"]) <= 1e-9
+    n = X.shape[0]; T = n // 128; mine = sum(8 for q in range(T // 8) if q %% world == rank)
+    assert abs(dg.matrix_bytes_ - (n + 128) * mine * 128 * 8) <= 4 * 128 * 128 * 8        # ~ 1/world of 2 GiB
+    print("rank", rank, dg.stats(), flush=True)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(1200)
+def test_config3_n16384_sharded_over_two_ranks(tmp_path):
+    """BASELINE configs[3] at its stated size (n = 16384, d = 16 fp64 RBF, W = 8) sharded over TWO ranks (host-pointer
+    transport, both on the box's one GPU): predictions, nlML, sigma_f == oracle on both ranks, matrix bytes halved; and
+    the protocol cost of the library's loop at world = 1 against the single-GPU entry point (printed; bound 10 %)."""
+    import time
+    import seaiceextentforecasting_amd as S
+    n, d = 16384, 16
+    X, y, Xs = O.synthetic_problem(n, d, 20240003, m=4)
+    ell, sn = np.sqrt(d), 1e-2
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind="rbf", ref_idiom=False)
+    np.savez(tmp_path / "ref.npz", X=X, y=y, Xs=Xs, ell=ell, sn=sn, fmean=ref["fmean"], fvar=ref["fvar"], nlml=ref["nlml"], sigma_f=ref["sigma_f"])
+    script = tmp_path / "worker.py"
+    script.write_text(_BIG_WORKER % dict(root=ROOT, out=str(tmp_path), ref=str(tmp_path / "ref.npz")))
+    p = _torchrun(script, 2, 29850 + (os.getpid() % 100), 900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+    # world = 1: the library's panel loop against sigp_fit_predict on the same handle size (best of 3 each)
+    def best(f):
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); f(); ts.append(time.perf_counter() - t0)
+        return min(ts)
+    with S.GPR(kernel="rbf") as gp:
+        gp.fit(X, y, ell, sn, Xs=Xs)
+        t_single = best(lambda: gp.refit(ell, sn))
+    with S.DistributedGPR("rbf", 0, 1, None, device=0, outer_blocks=8) as dg:
+        dg.fit(X, y, ell, sn, Xs=Xs)
+        t_shard = best(lambda: dg.refit(ell, sn))
+    print("n=16384 single-GPU fit %.2f ms, sigp_dist_fit at world=1 %.2f ms (%+.1f %%)" % (1e3 * t_single, 1e3 * t_shard, 100 * (t_shard / t_single - 1)))
+    assert t_shard <= 1.10 * t_single, (t_single, t_shard)
