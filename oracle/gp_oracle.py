@@ -224,19 +224,58 @@ def fit_predict(X, y, Xs, ell, sn_tilde, *, kind="netdiffusion", M=None, ref_idi
     return out
 
 
+def _tri_solve_blocked(L, B, trans=False, bs=2048):
+    """L x = B (or L^T x = B) for a large lower-triangular L by block substitution: diagonal blocks through LAPACK trtrs, the
+    rest through NumPy matmul (NumPy's BLAS takes 64-bit sizes; SciPy's LP64 LAPACK segfaults on a 32768 x 32768 matrix)."""
+    n = L.shape[0]
+    X = np.array(B, dtype=np.float64, copy=True)
+    starts = list(range(0, n, bs))
+    if not trans:
+        for i0 in starts:
+            i1 = min(n, i0 + bs)
+            X[i0:i1] = solve_triangular(L[i0:i1, i0:i1], X[i0:i1], lower=True, check_finite=False)
+            if i1 < n:
+                X[i1:] -= L[i1:, i0:i1] @ X[i0:i1]
+    else:
+        for i0 in reversed(starts):
+            i1 = min(n, i0 + bs)
+            X[i0:i1] = solve_triangular(L[i0:i1, i0:i1], X[i0:i1], lower=True, trans="T", check_finite=False)
+            if i0 > 0:
+                X[:i0] -= L[i0:i1, :i0].T @ X[i0:i1]
+    return X
+
+
+def _cholesky_blocked(K, bs=4096):
+    """In-place lower Cholesky of a large SPD matrix by the blocked right-looking algorithm LAPACK's potrf uses, spelled out
+    in NumPy / SciPy calls on blocks (this image's OpenBLAS 0.3.29 segfaults in potrf at n = 32768, in NumPy and SciPy alike):
+    diagonal block through ``np.linalg.cholesky``, the rows below through trsm, the trailing update through matmul, one block
+    column at a time so that temporaries stay at n x bs.  The strictly upper part is zeroed, as np.linalg.cholesky does."""
+    n = K.shape[0]
+    for j0 in range(0, n, bs):
+        j1 = min(n, j0 + bs)
+        K[j0:j1, j0:j1] = np.linalg.cholesky(K[j0:j1, j0:j1])
+        if j1 < n:
+            # L21 = A21 L11^-T  <=>  L11 L21^T = A21^T
+            K[j1:, j0:j1] = solve_triangular(K[j0:j1, j0:j1], K[j1:, j0:j1].T, lower=True, check_finite=False).T
+            for c0 in range(j1, n, bs):
+                c1 = min(n, c0 + bs)
+                K[c0:, c0:c1] -= K[c0:, j0:j1] @ K[c0:c1, j0:j1].T
+        K[j0:j1, j1:] = 0.0
+    return K
+
+
 def fit_predict_lean(X, y, Xs, ell, sn_tilde, *, kind="rbf", row_block=1024, threads=16):
     """The ``ref_idiom=False`` statements of :func:`fit_predict` (north/June1st.py:265-277, :246) for RBF / Matern at sizes
-    where its n x n temporaries do not fit: K~ is formed in place in row blocks (same arithmetic per entry: squared distances
-    by direct differences, then the covariance function), factored in place (``scipy.linalg.cholesky(overwrite_a=True)``),
-    and only the scalars of the block are returned: fmean, fvar, sigma_f, sigma_n, nlml, A_tilde.  One n x n float64 array
-    at peak (8 GiB at n = 32768).  Checked against :func:`fit_predict` in tests/test_oracle_golden.py."""
+    where its n x n temporaries do not fit: K~ is formed in row blocks (same arithmetic per entry: squared distances by
+    direct differences, then the covariance function), factored by ``np.linalg.cholesky`` as in the reference (:265; beyond
+    n = 16384 by the same blocked algorithm spelled out on blocks, ``_cholesky_blocked``), and only the scalars of the block
+    are returned: fmean, fvar, sigma_f, sigma_n, nlml, A_tilde.  At most two n x n float64 arrays at peak (16 GiB at n = 32768).  Checked against :func:`fit_predict` in tests/test_oracle_golden.py."""
     from concurrent.futures import ThreadPoolExecutor
-    from scipy.linalg import cholesky
     X = np.asarray(X, dtype=np.float64)
     y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
     Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
     n = len(y)
-    Kt = np.empty((n, n), order="F")                            # LAPACK's layout: potrf then works in place without a copy
+    Kt = np.empty((n, n))
 
     def rows(i0):
         i1 = min(n, i0 + row_block)
@@ -247,13 +286,13 @@ def fit_predict_lean(X, y, Xs, ell, sn_tilde, *, kind="rbf", row_block=1024, thr
 
     with ThreadPoolExecutor(max_workers=threads) as ex:
         list(ex.map(rows, range(0, n, row_block)))
-    L_tilde = cholesky(Kt, lower=True, overwrite_a=True, check_finite=False)           # :265
-    A_tilde = solve_triangular(L_tilde, y, lower=True, check_finite=False)
-    A_tilde = solve_triangular(L_tilde, A_tilde, lower=True, trans="T", check_finite=False)   # :266
+    L_tilde = _cholesky_blocked(Kt) if n > 16384 else np.linalg.cholesky(Kt)             # :265
+    del Kt
+    A_tilde = _tri_solve_blocked(L_tilde, _tri_solve_blocked(L_tilde, y), trans=True)    # :266
     sf = float(y[:, 0] @ A_tilde[:, 0]) / n                                              # :267
     sn = sf * sn_tilde                                                                   # :268
     ks = cov_unit(kind, X, Xs, ell)                                                      # :272 in unit signal variance
-    v = solve_triangular(L_tilde, ks, lower=True, check_finite=False)                    # :274 (L = sqrt(sf) L~)
+    v = _tri_solve_blocked(L_tilde, ks)                                                  # :274 (L = sqrt(sf) L~)
     fmean = ks.T @ A_tilde[:, 0]                                                         # :276 (k* alpha = k~* A~)
     fvar = sf * (1.0 + sn_tilde - np.sum(v * v, axis=0))                                 # :273, :277
     nlml = 0.5 * n + np.log(L_tilde.diagonal()).sum() + 0.5 * n * np.log(sf) + 0.5 * n * np.log(2 * np.pi)   # :246, y^T alpha = n

@@ -49,7 +49,7 @@ def load_golden(name):
 
 
 GOLDEN_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN)
-                      if f.endswith(".npz") and f != "callers.npz" and not f.startswith("networks_"))
+                      if f.endswith(".npz") and f != "callers.npz" and not f.startswith(("networks_", "config")))
 
 
 @pytest.fixture(params=GOLDEN_NAMES)

@@ -267,14 +267,19 @@ def test_config4_n32768_d32_fp32_matern_with_refinement(S):
         assert rel(a32, a64) <= 1e-6
         assert np.max(np.abs(Kr @ (a32 * g32.sigma_f_) - y[rows])) <= 1e-9 * np.max(np.abs(y))
         sf32, nl32 = g32.sigma_f_, g32.nlml_
-    # ... and against the ORACLE itself at the stated size (the memory-lean form of its ref_idiom=False statements: one 8 GiB
-    # matrix on the host, LAPACK potrf on all cores), not only against the HIP engine's own fp64 fit
-    import threadpoolctl
-    with threadpoolctl.threadpool_limits(limits=min(64, os.cpu_count() or 8)):
-        ref = O.fit_predict_lean(X, y, Xs, ell, sn, kind="matern52", threads=min(32, os.cpu_count() or 8))
+    # ... and against the ORACLE itself at the stated size, not only against the HIP engine's own fp64 fit: its numbers for exactly
+    # these inputs are the fixture tests/golden/config4_oracle.npz (tests/golden/make_golden_config4.py: fit_predict_lean, ~3 min
+    # of host time); SIGP_LIVE_ORACLE=1 recomputes them here instead
+    if os.environ.get("SIGP_LIVE_ORACLE") == "1":
+        ref = O.fit_predict_lean(X, y, Xs, ell, sn, kind="matern52", threads=8)
+        ref["A_tilde"] = ref["A_tilde"][:, 0]
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "config4_oracle.npz"))
+        assert (int(z["n"]), int(z["d"]), int(z["seed"]), int(z["m"])) == (n, d, 20240004, 2) and float(z["ell"]) == ell and float(z["sn"]) == sn
+        ref = {k: z[k] for k in ("fmean", "fvar", "sigma_f", "nlml", "A_tilde")}
     assert rel(mu, ref["fmean"]) <= 1e-6 and rel(var, ref["fvar"]) <= 1e-5, (rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
     assert rel(sf32, ref["sigma_f"]) <= 1e-6 and rel(nl32, ref["nlml"]) <= 1e-5
-    assert rel(a32 * sf32, ref["A_tilde"][:, 0]) <= 1e-6
+    assert rel(a32 * sf32, ref["A_tilde"]) <= 1e-6
     assert rel(mu64, ref["fmean"]) <= TOL_PRED and rel(var64, ref["fvar"]) <= TOL_PRED and rel(nl64, ref["nlml"]) <= 1e-9    # the fp64 engine at n = 32768, d = 32
 
 
@@ -589,14 +594,16 @@ for la in (True, False):
         dg.fit(X, y, np.sqrt(8.0), 1e-2, Xs=Xs)
         mu, var = dg.predict(Xs)
         st = dg.stats()
-    assert relf(mu, ref["fmean"]) <= 1e-8 and relf(var, ref["fvar"]) <= 1e-8 and relf(dg.nlml_, ref["nlml"]) <= 1e-9
+        nl = dg.nlml_
+    assert relf(mu, ref["fmean"]) <= 1e-8 and relf(var, ref["fvar"]) <= 1e-8 and relf(nl, ref["nlml"]) <= 1e-9
     assert st["collectives"] >= 5 + 2 and st["bcast_bytes"] > 0, st          # 5 panels + the two all-reduces went through RCCL
 Xf, yf, Xsf = O.synthetic_problem(900, 16, 515, m=2)
 reff = O.fit_predict(Xf, yf, Xsf, 4.0, 1e-1, kind="matern52", ref_idiom=False)
 with S.DistributedGPR("matern52", rank, world, dist, device=0, outer_blocks=2, dtype="f32", force_rccl=True) as dg:
     dg.fit(Xf, yf, 4.0, 1e-1, Xs=Xsf)
     mu, var = dg.predict(Xsf)
-    assert relf(mu, reff["fmean"]) <= 1e-6 and relf(var, reff["fvar"]) <= 1e-5 and 0 < dg.refine_residual_ <= 1e-10
+    resid = dg.refine_residual_
+assert relf(mu, reff["fmean"]) <= 1e-6 and relf(var, reff["fvar"]) <= 1e-5 and 0 < resid <= 1e-10
 # the collective itself: a device tensor through RCCL
 t = torch.arange(8, dtype=torch.float64, device="cuda")
 dist.broadcast(t, src=0); dist.all_reduce(t)

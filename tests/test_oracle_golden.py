@@ -4,6 +4,8 @@ Bar: every intermediate of the GP block to <= 1e-12 relative (sam
 same order, so in practice bit-equal or 1 ulp); MLII values incl. the inf branch; rounded retro outputs
 exactly equal.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -138,3 +140,23 @@ def test_config1_n64_d4_rbf_cpu_path():
     assert rel(a["fmean"], b["fmean"]) <= 1e-9 and rel(a["fvar"], b["fvar"]) <= 1e-9
     assert abs(float(y @ a["alpha"][:, 0]) - 64) < 1e-8 * 64
     assert np.all(a["fvar"] > 0)
+
+
+def test_lean_oracle_path_is_the_same_arithmetic():
+    """oracle.fit_predict_lean (row-block build, blocked Cholesky and block substitution for sizes where LAPACK's potrf in this
+    image's OpenBLAS segfaults) against oracle.fit_predict, and the committed configs[4] fixture's header."""
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+    for kind in ("rbf", "matern52"):
+        X, y, Xs = O.synthetic_problem(900, 8, 3, m=3)
+        a = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-2, kind=kind, ref_idiom=False)
+        b = O.fit_predict_lean(X, y, Xs, np.sqrt(8.0), 1e-2, kind=kind, row_block=128, threads=4)
+        assert rel(b["fmean"], a["fmean"]) <= 1e-11 and rel(b["fvar"], a["fvar"]) <= 1e-11
+        assert rel(b["nlml"], a["nlml"]) <= 1e-13 and rel(b["sigma_f"], a["sigma_f"]) <= 1e-13 and rel(b["A_tilde"], a["A_tilde"]) <= 1e-11
+    rng = np.random.default_rng(0)
+    A = rng.standard_normal((1500, 40)); K = A @ A.T; K[np.arange(1500), np.arange(1500)] += 5.0
+    assert rel(O._cholesky_blocked(K.copy(), bs=333), np.linalg.cholesky(K)) <= 1e-13
+    b = rng.standard_normal((1500, 3)); L = np.linalg.cholesky(K)
+    assert rel(O._tri_solve_blocked(L, b, bs=200), np.linalg.solve(L, b)) <= 1e-12
+    assert rel(O._tri_solve_blocked(L, b, trans=True, bs=200), np.linalg.solve(L.T, b)) <= 1e-12
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "config4_oracle.npz"))
+    assert int(z["n"]) == 32768 and int(z["d"]) == 32 and z["A_tilde"].shape == (32768,) and np.isfinite(float(z["nlml"]))
