@@ -79,6 +79,8 @@ struct GemmArgsT {
                                // then walks the flattened (member, tile) list w, w + grid.x, ... (member-major).  0 = one tile per workgroup.
   int ktri;                    // triangular operands: 1 = k starts at TM*bi (rows of A -- and of B in a lower SYRK -- are zero left of
                                // their diagonal block: upper-triangular factors), 2 = k stops after TN*(bj+1) (BT image upper-triangular)
+  int zshift;                  // lower, plain walk, batched: member z's trapezoid starts zshift*z rows lower (rows bi >= bj + zshift*z) -- the
+                               // block-cyclic column panels one rank owns in a sharded factor, updated in ONE launch (grid.y = own panel)
 };
 typedef GemmArgsT<double> GemmArgs;
 
@@ -144,8 +146,9 @@ __device__ inline bool gemm_tile_coords(const GemmArgsT<T>& g, int b, int& bi, i
   }
   if (g.patch <= 0) {
     int rem = b;
+    const int zoff = g.zshift * (int)blockIdx.y;
     for (int c = g.c0; c < g.c1; ++c) {
-      int lo = c > g.r0 ? c : g.r0;
+      int lo = c + zoff > g.r0 ? c + zoff : g.r0;
       int cnt = g.r1 - lo;
       if (cnt <= 0) continue;
       if (rem < cnt) { bj = c; bi = lo + rem; return true; }

@@ -65,10 +65,17 @@ template <typename TO, int DC = KB_DC>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
                                                      const KParams* __restrict__ kps, int flags_in, int colblk0 = 0) {
-  const int flags = flags_in & (DBG_MASK | 1 | 8);
+  const int flags = flags_in & (DBG_MASK | 1 | 8 | 16);
   const int full = flags & 1;      // flag bits 2 / 4: timing ablations (no covariance function / no store)
   int bi, bj;                      // 64-row tile, 128-column tile
-  if (flags & 8) {                 // "panel": the column blocks colblk0 .. colblk0 + gridDim.x of the lower triangle only (one rank's
+  long mcol = -1;                  // column of the tile in Mat when it is not the global one
+  if (flags & 16) {                // "cyclic": ALL block columns one rank owns in a matrix sharded by block-cyclic panels, in one launch:
+    const int W = colblk0 & 255, world = (colblk0 >> 8) & 255, rank = (colblk0 >> 16) & 255;   // local block column x = blockIdx.x of
+    bi = blockIdx.y;                                                                           // Mat [rows][own columns] is global block
+    bj = ((int)blockIdx.x / W * world + rank) * W + (int)blockIdx.x % W;                       // column (x / W world + rank) W + x % W
+    if (bi * KB_TM + KB_TM <= bj * KB_TN) return;
+    mcol = (long)blockIdx.x * KB_TN;
+  } else if (flags & 8) {          // "panel": the column blocks colblk0 .. colblk0 + gridDim.x of the lower triangle only (one rank's
     bi = blockIdx.y; bj = colblk0 + blockIdx.x;   // share of a matrix sharded by block columns); Mat is the virtual origin of the
     if (bi * KB_TM + KB_TM <= bj * KB_TN) return; // local storage, so global (row, column) indexing lands in it
   } else if (full) {
@@ -130,7 +137,7 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
       if (gi >= n) o.v[c] = (TO)((gi == gj + c && !full) ? 1.0 : 0.0);
       else o.v[c] = (TO)((gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq(kp, acc[s][c])) + (gi == gj + c ? kp.sn : 0.0) : 0.0);
     }
-    if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + gj) = o;
+    if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + (mcol >= 0 ? mcol + c4 : (long)gj)) = o;
   }
 }
 
@@ -142,10 +149,18 @@ __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restric
                                                          long strideXs, const double* __restrict__ y, long stridey, int dp, int d,
                                                          int n, int n_pad, int m, int first_row, TO* __restrict__ Z,
                                                          long strideZ, long ld, const KParams* __restrict__ kps, int compute_cov,
-                                                         int i0 = 0, int icount = -1) {
-  const int i = i0 + blockIdx.x * 256 + threadIdx.x;   // column (training point); [i0, i0 + icount): one rank's block columns
+                                                         int i0 = 0, int icount = -1, int cyclic = 0) {
+  int i = i0 + blockIdx.x * 256 + threadIdx.x;         // column (training point); [i0, i0 + icount): one rank's block columns
   const int r = blockIdx.y;                            // row of the ride block
-  if (i >= n_pad || (icount >= 0 && i >= i0 + icount)) return;
+  long zcol = -1;
+  if (cyclic) {                                        // all own columns of a block-cyclic sharding at once (cyclic = W | world << 8 | rank << 16):
+    const int W = cyclic & 255, world = (cyclic >> 8) & 255, rank = (cyclic >> 16) & 255;      // local column i of Z [128][icount] is global column ...
+    if (i >= icount) return;
+    zcol = i;
+    const int x = i >> 7;
+    i = (((x / W) * world + rank) * W + x % W) * 128 + (i & 127);
+  }
+  if (i >= n_pad || (!cyclic && icount >= 0 && i >= i0 + icount)) return;
   const KParams kp = kps[blockIdx.z];
   X += kp.ds * strideX;
   Xs += kp.ds * strideXs;
@@ -165,7 +180,7 @@ __global__ __launch_bounds__(256) void ride_build_kernel(const double* __restric
       return;   // rows were produced by a GEMM (reference kernel); only row 0 / padding handled here
     }
   }
-  Z[(long)r * ld + i] = (TO)v;
+  Z[(long)r * ld + (zcol >= 0 ? zcol : (long)i)] = (TO)v;
 }
 
 // after a GEMM-form build (reference kernel): add sn on the diagonal, identity on the padding
@@ -233,13 +248,20 @@ __global__ __launch_bounds__(256) void epilogue_kernel(const TI* __restrict__ W,
 
 // sum_i log L_ii over the diagonal entries [i0, i0 + icount) n (i < n) of a matrix given by its virtual origin (one rank's
 // block columns of a factor sharded by columns); accumulates into *out (one block)
+// cyclic = W | world << 8 | rank << 16: Mat [rows][ncol] holds the rank's own block columns side by side; one block walks them all
+// in order (a fixed summation order), *out = the sum.
 template <typename TI>
-__global__ __launch_bounds__(256) void logdiag_window_kernel(const TI* __restrict__ Mat, long ld, int n, int i0, int icount, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void logdiag_cyclic_kernel(const TI* __restrict__ Mat, long ld, int n, int ncol, int cyclic, double* __restrict__ out) {
   __shared__ double sh[4];
+  const int W = cyclic & 255, world = (cyclic >> 8) & 255, rank = (cyclic >> 16) & 255;
   double a = 0.0;
-  for (int i = i0 + threadIdx.x; i < i0 + icount && i < n; i += 256) a += log((double)Mat[(long)i * ld + i]);
+  for (int c = threadIdx.x; c < ncol; c += 256) {
+    const int x = c >> 7;
+    const int i = (((x / W) * world + rank) * W + x % W) * 128 + (c & 127);     // global column = row of the diagonal entry
+    if (i < n) a += log((double)Mat[(long)i * ld + c]);
+  }
   a = block_reduce_sum(a, sh);
-  if (threadIdx.x == 0) *out += a;
+  if (threadIdx.x == 0) *out = a;
 }
 
 // copy a [rows][cols] block (device -> device) with different strides
@@ -249,6 +271,18 @@ __global__ void copy_block_kernel(const double* __restrict__ src, long lds, doub
   if (idx >= (long)rows * cols) return;
   const int r = (int)(idx / cols), c = (int)(idx % cols);
   dst[(long)r * ldd + c] = src[(long)r * lds + c];
+}
+
+// pack a [rows][row_bytes] block into a contiguous buffer (sharded fit: a factored panel -> the broadcast buffer): 16-byte
+// accesses, one 256-thread block per 4 rows (hipMemcpy2DAsync device-to-device runs a fraction of this rate on strided rows).
+// row_bytes and both strides are multiples of 16.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const char* __restrict__ src, long src_stride, char* __restrict__ dst, long dst_stride, long rows, int row_bytes) {
+  const int nv = row_bytes >> 4;
+  for (long r = (long)blockIdx.x * 4; r < min(rows, (long)blockIdx.x * 4 + 4); ++r) {
+    const uint4* s = (const uint4*)(src + r * src_stride);
+    uint4* d = (uint4*)(dst + r * dst_stride);
+    for (int v = threadIdx.x; v < nv; v += 256) d[v] = s[v];
+  }
 }
 
 // panel_mode 1: diagonal blocks of the Mt workspace = the inverse diagonal blocks of the panel (grid: block j, member)

@@ -125,7 +125,7 @@ struct sigp_handle {
     hipStream_t s_comm = nullptr;              // the panel broadcasts run here, beside the update and panel streams
     void* hstage = nullptr; size_t cap_hstage = 0;   // pinned staging buffer of a host-pointer transport
     void* pbuf[2] = {nullptr, nullptr}; size_t cap_pbuf = 0;   // two packed-panel buffers in rotation (device)
-    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_mark = nullptr;
+    hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_first[2] = {nullptr, nullptr}, ev_mark = nullptr;
     std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
     // sharded triangular solves of the fp32 refinement: inverses of the own panels' diagonal blocks, panel-major work vectors
     float* Uinv = nullptr; float* Vinv = nullptr; size_t cap_inv = 0;        // [own panel][PW][PW] each (upper: L_pp^-T, lower: L_pp^-1)
@@ -134,7 +134,7 @@ struct sigp_handle {
     double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
-    double st_collectives = 0;
+    double st_collectives = 0, st_host_comm_ms = 0, st_enqueue_ms = 0;
   } dc;
   int opt_dist_stats = 0;                      // time the broadcasts and the update stream's waits for them with HIP events
   int opt_owner_only = 0;                      // sigp_set_train does not allocate the full n x n slot matrix
@@ -453,10 +453,10 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   if (nt * 4 <= h->opt_tiny_tiles && g.K <= 2 * NB) {   // so few 64-tiles that most SIMDs would idle: 32x32 tiles, a quarter of the MFMA chain per
                                                         // wave.  Short K only: at K = 1024 the 32x32 tiles' operand traffic (4 flop/B) is what the
                                                         // launch waits for (53-61 us for the 41-tile update before the last panel of n = 4096)
-    g.r0 *= 4; g.r1 *= 4; g.c0 *= 4; g.c1 *= 4;
+    g.r0 *= 4; g.r1 *= 4; g.c0 *= 4; g.c1 *= 4; g.zshift *= 4;
     return launch_gemm_cfg<T, 32, 32, 2, 2, GEMM_SUB, false>(h, st, g);
   }
-  g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2;   // same region in 64-units
+  g.r0 *= 2; g.r1 *= 2; g.c0 *= 2; g.c1 *= 2; g.zshift *= 2;   // same region in 64-units
   return launch_gemm_cfg<T, 64, 64, 2, 2, GEMM_SUB, false>(h, st, g);
 }
 
@@ -859,8 +859,14 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStrea
       g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
       g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
       g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
-      g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
-      if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g))) return rc;
+      g.batch = 1; g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
+      if (rows_below >= h->opt_trsm128) {          // enough 128-row tiles to fill the chip: the LDS-DMA kernel (as potrf_core's solve_column)
+        g.r1 = rows_below;
+        if ((rc = launch_syrk128_t<Real, true>(h, sp, g))) return rc;
+      } else {
+        g.r1 = rows_below * 4;
+        if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g))) return rc;
+      }
     }
     if (i + 1 >= Wp) break;
     if ((rc = gemm_sub_auto(h, sp, upd_args(c, c + 1, 0, 1)))) return rc;
@@ -891,7 +897,9 @@ int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipS
     g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
     g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
     g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
-    g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = rows_below * 4; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    g.batch = 1; g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    if (rows_below >= h->opt_trsm128) { g.r1 = rows_below; return launch_syrk128_t<Real, true>(h, sp, g); }
+    g.r1 = rows_below * 4;
     return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
   }
   const int hw = Wp / 2;
@@ -1911,7 +1919,8 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   }
   const struct { const char* nm; const double* v; } ds[] = {
       {"dist_fit_ms", &h->dc.st_fit_ms}, {"dist_factor_ms", &h->dc.st_factor_ms}, {"dist_bcast_bytes", &h->dc.st_bcast_bytes}, {"dist_comm_ms", &h->dc.st_comm_ms},
-      {"dist_stall_ms", &h->dc.st_stall_ms}, {"dist_solve_ms", &h->dc.st_solve_ms}, {"dist_collectives", &h->dc.st_collectives}};
+      {"dist_stall_ms", &h->dc.st_stall_ms}, {"dist_solve_ms", &h->dc.st_solve_ms}, {"dist_collectives", &h->dc.st_collectives},
+      {"dist_host_comm_ms", &h->dc.st_host_comm_ms}, {"dist_enqueue_ms", &h->dc.st_enqueue_ms}};
   for (const auto& e : ds)
     if (!strcmp(name, e.nm)) { *value = *e.v; return SIGP_OK; }
   if (!strcmp(name, "dist_comm_ranks")) {        // what the communicator itself reports (ncclCommCount); 0 = no RCCL communicator on this handle

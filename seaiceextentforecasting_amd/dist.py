@@ -274,7 +274,7 @@ class DistributedGPR:
 
     def stats(self):
         """``dist_*`` statistics of the last fit (meaningful with ``stats=True``): ms and bytes on THIS rank."""
-        return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks")}
+        return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks", "host_comm_ms", "enqueue_ms")}
 
     def predict(self, Xs):
         if self._own_ride is None:
