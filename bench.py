@@ -101,7 +101,6 @@ def main():
     ap.add_argument("--concurrency", type=int, default=1, help="lockstep groups in flight")
     ap.add_argument("--group", type=int, default=40, help="fits factorised in lockstep per launch")
     ap.add_argument("--outer", type=int, default=8, help="outer panel width in 128-column blocks (K of the trailing update = 128*outer)")
-    ap.add_argument("--reserve-cus", type=int, default=None)
     ap.add_argument("--host-timing", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -171,7 +170,7 @@ def main():
     sn = np.array([grid_point(int(s), d, args.grid)[1] for s in fit_step])
     K, W = len(my_fits) - n_warm, n_warm    # this rank's timed / warm-up FITS
 
-    gp = GPR(kernel="rbf", device=local, outer_blocks=args.outer, reserve_cus=args.reserve_cus)
+    gp = GPR(kernel="rbf", device=local, outer_blocks=args.outer)
     for o in args.opt:
         k, v = o.split("=")
         gp.set_option(k, int(v))
@@ -509,6 +508,25 @@ def other_configs(local):
             fl = mlii_flops(n, 8)
             ml["n=%d" % n] = {"ms": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
                               "algorithmic_flops": fl}
+    # the same evaluation for the 40 retrospective years in lockstep (sigp_nlml_grad_batch): what a multi-start optimiser calls per iteration
+    try:
+        for n, G in ((4096, 40), (8192, 40)):
+            Xb = np.zeros((G, n, 8)); yb = np.zeros((G, n))
+            for b in range(G):
+                Xb[b], yb[b], _ = synthetic_problem(n, 8, 20240002 + b, m=1)
+            th = np.tile(np.log([np.sqrt(8.0), 1e-2]), (G, 1))
+            with GPR(kernel="rbf", device=local) as g:
+                g.upload_batch(Xb, yb, None, group=G, concurrency=1)
+                g.nlml_batch(th, grad="exact", group=G)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                g.nlml_batch(th, grad="exact", group=G)
+                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / G
+            fl = mlii_flops(n, 8)
+            ml["n=%d lockstep group of %d" % (n, G)] = {"ms_per_evaluation": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
+                                                      "evaluations_per_s": 1.0 / dt}
+            del Xb, yb
+    except Exception as e:                       # noqa: BLE001 -- an extra record must never cost the metric line
+        ml["lockstep_error"] = "%s: %s" % (type(e).__name__, str(e)[:200])
     rec["reference_kernel_grid"] = reference_kernel_grid(local)
     ml["note"] = "one MLII evaluation = fit (n^3/3) + L~^-T by recursive triangular inversion (n^3/3) + lower K~^-1 = U U^T (n^3/3) + O(n^2 d) derivative/reductions"
     rec["mlii"] = ml

@@ -179,6 +179,16 @@ int sigp_get_matrix(sigp_handle* h, int which, double* out, int64_t ldo);
 int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const double* Sigma,
                    const double* MSigma, int64_t ldsigma, int grad_mode, double* nlml, double grad[2]);
 
+/* MLII for a lockstep group of fits on the data sets resident after sigp_batch_upload (RBF / Matern, fp64): value and EXACT gradient
+ * of the profiled nlML (north/June1st.py:235-257 with the true derivative = sigp_nlml_grad's grad_mode 2) for `count` (data set,
+ * theta) pairs; fit i uses data set (first + i) % batch and theta[2i .. 2i+1] = (log ell, log sn~).  Groups of `group` members
+ * (sigp_set_option) advance through every launch together: build, blocked Cholesky, L~^-T by recursive triangular inversion,
+ * K~^-1 = U U^T, A~ = U z, reductions with dK~/dlog ell recomputed on the fly.  One call per optimiser iteration serves every
+ * retrospective year (the call the reference left commented out, north/June1st.py:259-262, batched over the retro loop of
+ * north/retrospective_forecasts/September1st_retro.py:176-248).  grad_mode 0 (value only; grad may be NULL) or 2.
+ * nlml [count], grad [count][2]; a non-SPD member gets +inf in both (the reference's except branch :254-256). */
+int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* theta, int grad_mode, double* nlml, double* grad);
+
 /* One large fit sharded over the GPUs of a node (BASELINE configs[3] fp64, configs[4] fp32 + fp64 refinement): 1-D block-cyclic
  * ownership of outer panels (W column blocks of 128; panel q belongs to rank q % nranks), OWNER-ONLY storage -- a rank allocates,
  * builds and updates only the block columns of its own panels (per-rank matrix bytes ~ 1/nranks) -- and the block-row panel
@@ -240,24 +250,20 @@ int sigp_profile_reset(sigp_handle* h);
  *   lookahead [1]         factor the next panel on the panel stream while the trailing update runs
  *   schedule [0]          0 right-looking outer panels, 1 left-looking (same factor bit for bit)
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
- *   panel_ll [0]          panels up to this width are factored left-looking inside
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit
- *   tile walks of the trailing update -- placement only, results bit-identical; all measured slower than the default and left off
- *   (DESIGN.md section 7):  xcd_chunks [0] (P: 64-tile chunks of PxP patches per XCD), update_wgs [0] (persistent grid of this many
- *   workgroups) with update_late [0] (only for the last k panels), pipeline_head [0] (two lockstep groups in flight: 1 = only the next
- *   group's build + first panel overlap the current group, 2 = only its build, 3 = the head starts when the current group has head_gate
- *   [16] block columns left), small_nt64 [0] (one wavefront per fit in sigp_small_run),
- *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it)
+ *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:
+ *   the trailing-update kernel's own rate, bench.py's roofline.unshared)
  *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [3] (bit 0: panels that are not strip-solved,
  *   bit 1: top blocks of strip-solved panels, are factored column by column with the other columns' update riding in the diagonal-block
  *   launch; 0 = binary recursion), chain_rows [80] (bit 0 applies while rows-below x members <= this), first_on_panel [1] (the update of
- *   the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always), wide_tiles [0] (trailing updates on
- *   128 x 256 workgroup tiles, syrk_wide_kernel: bit 0 fp64, bit 1 fp32; bit-identical, measured slower / neutral), n64_tiles [0]
- *   (128 x 64 tiles, three workgroups per CU, syrk_n64_kernel; same bits, same verdict)
- *   pan_priority, diag_prio, patch, reserve_cus, host_timing   measurement switches; c_dma, syrk_v2: libsigp_debug.so only */
+ *   the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always)
+ *   pan_priority, diag_prio, host_timing   measurement switches
+ * The rejected experiments of DESIGN.md section 7 (xcd_chunks, update_wgs / update_late, pipeline_head / head_gate, wide_tiles, n64_tiles,
+ * patch, small_nt64, reserve_cus, panel_ll, c_dma, syrk_v2) are compiled into libsigp_debug.so only (make debug; include/sigp_debug.h):
+ * the product library answers SIGP_BAD_ARG to their names and carries none of their kernels. */
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value);
 
 #ifdef __cplusplus

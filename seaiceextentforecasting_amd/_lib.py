@@ -52,6 +52,7 @@ SIGNATURES = {
     "sigp_get_alpha": (C.c_int, [_h, _dp]),
     "sigp_get_matrix": (C.c_int, [_h, C.c_int, _dp, _i64]),
     "sigp_nlml_grad": (C.c_int, [_h, C.c_int, _dp, _dp, _dp, _i64, C.c_int, C.POINTER(C.c_double), _dp]),
+    "sigp_nlml_grad_batch": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, C.c_int, _dp, _dp]),
     "sigp_dist_unique_id": (C.c_int, [C.c_void_p]),
     "sigp_dist_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "sigp_dist_init_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),

@@ -79,6 +79,7 @@ struct GemmArgsT {
                                // then walks the flattened (member, tile) list w, w + grid.x, ... (member-major).  0 = one tile per workgroup.
   int ktri;                    // triangular operands: 1 = k starts at TM*bi (rows of A -- and of B in a lower SYRK -- are zero left of
                                // their diagonal block: upper-triangular factors), 2 = k stops after TN*(bj+1) (BT image upper-triangular)
+  int zcount; long zA, zB, zC; // a second batch dimension (grid.z, strides in elements): lockstep members x (pairs of a level | panels)
   int zshift;                  // lower, plain walk, batched: member z's trapezoid starts zshift*z rows lower (rows bi >= bj + zshift*z) -- the
                                // block-cyclic column panels one rank owns in a sharded factor, updated in ONE launch (grid.y = own panel)
 };
@@ -244,9 +245,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgsT<T>& g, int bi, in
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 15, lq = lane >> 4;
 
-  const T* Ag = g.A + bz * g.sA + (long)bi * TM * g.lda;
-  const T* Bg = BT ? g.B + bz * g.sB + (long)bj * TN : g.B + bz * g.sB + (long)bj * TN * g.ldb;
-  T* Cg = g.C + bz * g.sC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
+  const long zz = (long)blockIdx.z;
+  const T* Ag = g.A + bz * g.sA + zz * g.zA + (long)bi * TM * g.lda;
+  const T* Bg = BT ? g.B + bz * g.sB + zz * g.zB + (long)bj * TN : g.B + bz * g.sB + zz * g.zB + (long)bj * TN * g.ldb;
+  T* Cg = g.C + bz * g.sC + zz * g.zC + ((long)bi * TM + wm * WTM) * g.ldc + (long)bj * TN + wn * WTN;
 
   acc_t acc[FM][FN];
 #pragma unroll

@@ -29,6 +29,7 @@ __constant__ ExpCoef kExpCoef = {1.44269504088896338700e+00, 6.93147180369123816
                                  {1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
                                   1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0}};
 __device__ __forceinline__ double exp_cov(double x) {
+  x = fmax(x, -746.0);               // exp underflows to 0 below this: keeps k in int range and r accurate for any length scale (l -> 0, x -> -inf)
   const double k = __builtin_rint(x * kExpCoef.l2e);
   double r = fma(-k, kExpCoef.ln2hi, x);
   r = fma(-k, kExpCoef.ln2lo, r);
@@ -297,10 +298,10 @@ __global__ void mt_diag_kernel(const T* __restrict__ dinv, long dinvStride, T* _
 // U[b][b] = dinv[b]^T for every 128-block b of the diagonal (one workgroup per block, through LDS so that both sides are
 // coalesced): the leaves of the recursive triangular inversion in sigp_nlml_grad.
 template <typename T>
-__global__ __launch_bounds__(256) void transpose_blocks_kernel(const T* __restrict__ dinv, T* __restrict__ U, long ld) {
+__global__ __launch_bounds__(256) void transpose_blocks_kernel(const T* __restrict__ dinv, T* __restrict__ U, long ld, long sD = 0, long sU = 0) {
   __shared__ T tile[32][33];
-  const T* src = dinv + (long)blockIdx.x * 128 * 128;
-  T* dst = U + (long)blockIdx.x * 128 * (ld + 1);
+  const T* src = dinv + (long)blockIdx.y * sD + (long)blockIdx.x * 128 * 128;      // blockIdx.y = lockstep member
+  T* dst = U + (long)blockIdx.y * sU + (long)blockIdx.x * 128 * (ld + 1);
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
   for (int bi = 0; bi < 4; ++bi)
     for (int bj = 0; bj < 4; ++bj) {
@@ -336,6 +337,79 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* __restri
   }
 }
 
+// The same reductions for a lockstep group of RBF / Matern fits (sigp_nlml_grad_batch), the derivative matrix D = dK~/dlog l
+// computed on the fly from X (never stored): blockIdx.y = member, one block per GR_ROWS rows, lower triangle only (D is
+// symmetric with a zero diagonal for both kernels: a^T D a = 2 sum_{j<i} a_i D_ij a_j).  kps[member] carries the *_DLOGL
+// covariance id and the data set.  part [member][rows][4] as above.
+constexpr int GR_ROWS = 4;
+__global__ __launch_bounds__(256) void grad_reduce_cov_kernel(const double* __restrict__ Kinv, long sK, long ld, const double* __restrict__ a, long sa,
+                                                              const double* __restrict__ X, long strideX, int dp, int d, int n,
+                                                              const KParams* __restrict__ kps, double* __restrict__ part, long spart) {
+  __shared__ double Xi[GR_ROWS][65];
+  __shared__ double sh[4];
+  const KParams kp = kps[blockIdx.y];
+  X += kp.ds * strideX;
+  Kinv += (long)blockIdx.y * sK; a += (long)blockIdx.y * sa; part += (long)blockIdx.y * spart;
+  const int i0 = blockIdx.x * GR_ROWS;
+  for (int idx = threadIdx.x; idx < GR_ROWS * d; idx += 256) {
+    const int r = idx / d, p = idx % d;
+    Xi[r][p] = (i0 + r < n) ? X[(long)(i0 + r) * dp + p] : 0.0;
+  }
+  __syncthreads();
+  double t[GR_ROWS], q[GR_ROWS];
+#pragma unroll
+  for (int r = 0; r < GR_ROWS; ++r) { t[r] = 0.0; q[r] = 0.0; }
+  const int jmax = min(n, i0 + GR_ROWS);                   // j < i for the last row of the block
+  for (int j = threadIdx.x; j < jmax; j += 256) {
+    double sq[GR_ROWS];
+#pragma unroll
+    for (int r = 0; r < GR_ROWS; ++r) sq[r] = 0.0;
+    const double* xj = X + (long)j * dp;
+    for (int p = 0; p < d; ++p) {
+      const double v = xj[p];
+#pragma unroll
+      for (int r = 0; r < GR_ROWS; ++r) { const double u = Xi[r][p] - v; sq[r] = fma(u, u, sq[r]); }
+    }
+    const double aj = a[j];
+#pragma unroll
+    for (int r = 0; r < GR_ROWS; ++r) {
+      const int i = i0 + r;
+      if (j < i && i < n) {
+        const double dij = cov_from_sq(kp, sq[r]);
+        t[r] = fma(2.0 * Kinv[(long)i * ld + j], dij, t[r]);
+        q[r] = fma(dij, aj, q[r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < GR_ROWS; ++r) {
+    const double ts = block_reduce_sum(t[r], sh);
+    const double qs = block_reduce_sum(q[r], sh);
+    const int i = i0 + r;
+    if (threadIdx.x == 0 && i < n) {
+      const double ai = a[i];
+      part[4 * (long)i + 0] = ts;                            // row i's share of tr(K~^-1 D)   (D_ii = 0)
+      part[4 * (long)i + 1] = 2.0 * ai * qs;                 // row i's share of a^T D a
+      part[4 * (long)i + 2] = Kinv[(long)i * ld + i];
+      part[4 * (long)i + 3] = ai * ai;
+    }
+  }
+}
+// out [member][4] = column sums of part [member][n][4], one block per member, rows added in a fixed order
+__global__ __launch_bounds__(256) void grad_sum_kernel(const double* __restrict__ part, long spart, int n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  part += (long)blockIdx.x * spart;
+  double s4[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) s4[c] += part[4 * (long)i + c];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const double v = block_reduce_sum(s4[c], sh);
+    if (threadIdx.x == 0) out[4 * blockIdx.x + c] = v;
+  }
+}
+
 // ---- block triangular solves with a handful of right-hand sides -------------------------------------------------------
 // (fp32 engine: x = L^-T L^-1 r of every refinement step, north/June1st.py:266 in preconditioner form.)  The factor is cut
 // into big column blocks of TS_BS whose diagonal blocks carry explicit inverses (trtri_levels with span = TS_BS/128), so a
@@ -360,9 +434,11 @@ template <> struct Vec16<double> { typedef d2 type; static constexpr int N = 2; 
 template <typename T>
 __global__ __launch_bounds__(256) void rowdot_kernel(const T* __restrict__ Mx, long ld, int nrows, int K, int kmode,
                                                      const T* __restrict__ Zin, long ldzin, T* __restrict__ Zout, long ldzout,
-                                                     int nrhs, int sub, const T* __restrict__ Zadd = nullptr, int pm_pw = 0, int j_off = 0) {
+                                                     int nrhs, int sub, const T* __restrict__ Zadd = nullptr, int pm_pw = 0, int j_off = 0,
+                                                     long sM = 0, long sZi = 0, long sZo = 0) {
   typedef typename Vec16<T>::type V;
   constexpr int NV = Vec16<T>::N;
+  Mx += (long)blockIdx.y * sM; Zin += (long)blockIdx.y * sZi; Zout += (long)blockIdx.y * sZo;      // blockIdx.y = lockstep member
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.x * 4 + wave;
   if (j >= nrows) return;

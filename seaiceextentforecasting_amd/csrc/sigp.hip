@@ -76,6 +76,7 @@ struct sigp_handle {
   double* gK = nullptr; long cap_gK = 0;
   double* gD = nullptr; long cap_gD = 0;
   double* gPart = nullptr; long cap_gPart = 0;
+  KParams* gKps = nullptr; int cap_gKps = 0;  // derivative-covariance parameters of a lockstep MLII group
   double* gSig = nullptr; long cap_gSig = 0;  // MLII gradient (reference kernel): M Sigma~ padded [dp][dp] and X (M Sigma~) [n_pad][dp] --
   double* gT = nullptr; long cap_gT = 0;      // separate from Sig / T, which sigp_predict reads after a fit
   // fp32 engine (dtype == SIGP_F32): fp32 factor + fp64 iterative refinement (BASELINE configs[4])
@@ -371,7 +372,7 @@ int launch_gemm_cfg(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g) {
   constexpr int lds = gemm_lds_bytes<T, TM, TN, BT>();
   static AttrOnce attr;
   HIPCHK(h, attr.set(h->device, (const void*)kern, lds));
-  hipLaunchKernelGGL(kern, dim3(nt, std::max(1, g.batch)), dim3(256), lds, st, g);
+  hipLaunchKernelGGL(kern, dim3(nt, std::max(1, g.batch), std::max(1, g.zcount)), dim3(256), lds, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
@@ -385,6 +386,7 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
   if (nt <= 0) return SIGP_OK;
   static AttrOnce attr;
   HIPCHK(h, attr.set(h->device, (const void*)syrk128_kernel<T, SET>, SY_LDS_BYTES));
+#ifdef SIGP_DEBUG_TOOLS   // tile-walk experiments (persistent grid, XCD-chunked walk): measured slower, libsigp_debug.so only
   const long total = (long)nt * std::max(1, g.batch);
   if (may_persist && h->persist_now && h->opt_update_wgs > 0 && g.patch == 0 && total > h->opt_update_wgs) {
     GemmArgsT<T> gp = g;
@@ -402,7 +404,10 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
     HIPCHK(h, hipGetLastError());
     return SIGP_OK;
   }
-  hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch)), dim3(256), SY_LDS_BYTES, st, g);
+#else
+  (void)may_persist;
+#endif
+  hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch), std::max(1, g.zcount)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
 }
@@ -422,6 +427,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1)) * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
+#ifdef SIGP_DEBUG_TOOLS
     // 128 x 256 workgroup tiles (syrk_wide_kernel): lower updates over an even number of column blocks, plain walk
     const int wide = sizeof(T) == 4 ? (h->opt_wide_tiles & 2) : (h->opt_wide_tiles & 1);
     if (wide && g.lower && g.patch == 0 && g.ktri == 0 && ((g.c1 - g.c0) & 1) == 0 && !h->persist_now && h->opt_xcd_chunks == 0 &&
@@ -442,6 +448,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
       HIPCHK(h, hipGetLastError());
       return SIGP_OK;
     }
+#endif
     if (h->opt_c_dma) g.dbg |= 128;
     return launch_syrk128_t<T, false>(h, st, g, true);   // tile-walk options (xcd_chunks, update_wgs when persist_now) apply here
   }
@@ -1016,12 +1023,14 @@ static int solve_rows_backward(sigp_handle* h, Slot& s, double* Z, long n_pad) {
 // 128-blocks): span >= T inverts the whole factor, span = S leaves the inverses of the aligned S-block diagonal blocks
 // (what the block triangular solves of the fp32 refinement use).  P is scratch of the same shape as U.
 // Blocks of U below its block diagonal are never written NOR read (the products skip them through GemmArgsT::ktri).
+// nz > 1: nz lockstep members in every launch (grid.z; member strides zL, zD, zU of Lm, dinvp and of U / P).
 template <typename Real>
-int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const Real* dinvp, Real* U, Real* P, long ld, int T, int span) {
+int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const Real* dinvp, Real* U, Real* P, long ld, int T, int span,
+                 int nz = 1, long zL = 0, long zD = 0, long zU = 0) {
   // Lm has its own leading dimension ldl (a rank's block columns of a sharded factor: the diagonal block of one of its panels
   // sits in storage whose row stride is its column count); U and P share ld
   int rc;
-  hipLaunchKernelGGL(transpose_blocks_kernel<Real>, dim3(T), dim3(256), 0, st, dinvp, U, ld);
+  hipLaunchKernelGGL(transpose_blocks_kernel<Real>, dim3(T, nz), dim3(256), 0, st, dinvp, U, ld, zD, zU);
   HIPCHK(h, hipGetLastError());
   for (int sblk = 1; sblk < T && sblk < span; sblk *= 2) {
     const int npairs_full = T / (2 * sblk);                           // pairs whose right block is a whole s-block
@@ -1039,12 +1048,14 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const
       g1.B = Lm + oL + (long)sblk * NB * ldl; g1.ldb = ldl; g1.sB = pairStrideL;
       g1.C = P + o + (long)sblk * NB; g1.ldc = ld; g1.sC = pairStride;
       g1.batch = nb2; g1.K = sblk * NB; g1.r0 = 0; g1.r1 = sblk; g1.c0 = 0; g1.c1 = rs; g1.lower = 0; g1.ktri = 1;
+      g1.zcount = nz; g1.zA = zU; g1.zB = zL; g1.zC = zU;
       if ((rc = launch_syrk128_t<Real, true>(h, st, g1))) return rc;
       GemmArgsT<Real> g2{};                                           // U12 = -P U22
       g2.A = P + o + (long)sblk * NB; g2.lda = ld; g2.sA = pairStride;
       g2.B = U + o + (long)sblk * NB * (ld + 1); g2.ldb = ld; g2.sB = pairStride;
       g2.C = U + o + (long)sblk * NB; g2.ldc = ld; g2.sC = pairStride;
       g2.batch = nb2; g2.K = rs * NB; g2.r0 = 0; g2.r1 = sblk; g2.c0 = 0; g2.c1 = rs; g2.lower = 0; g2.ktri = 2;
+      g2.zcount = nz; g2.zA = zU; g2.zB = zU; g2.zC = zU;
       if ((rc = launch_gemm_cfg<Real, 128, 128, 2, 2, GEMM_SETNEG, true>(h, st, g2))) return rc;
     }
   }
@@ -1099,6 +1110,7 @@ int sigp_destroy(sigp_handle* h) {
   if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
   if (h->sm_probs) (void)hipFree(h->sm_probs);
   if (h->pred_kps) (void)hipFree(h->pred_kps);
+  if (h->gKps) (void)hipFree(h->gKps);
   if (h->fmat) (void)hipFree(h->fmat);
   if (h->fdinv) (void)hipFree(h->fdinv);
   if (h->fZ) (void)hipFree(h->fZ);
@@ -1112,6 +1124,13 @@ const char* sigp_last_error(const sigp_handle* h) { return h ? h->err.c_str() : 
 
 int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!h || !name) return SIGP_BAD_ARG;
+  {   // measurement switches and rejected experiments: their code is compiled into libsigp_debug.so only
+    static const char* const dbg_only[] = {"xcd_chunks", "update_wgs", "update_late", "pipeline_head", "head_gate", "wide_tiles", "n64_tiles", "patch",
+                                           "small_nt64", "reserve_cus", "panel_ll", "c_dma", "syrk_v2"};
+    if (!DBG_MASK)
+      for (const char* nm : dbg_only)
+        if (!strcmp(name, nm)) return fail(h, SIGP_BAD_ARG, "%s is a measurement switch of libsigp_debug.so (make debug), not of the product library", nm);
+  }
   if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_outer = (int)value; return SIGP_OK; }
   if (!strcmp(name, "lookahead")) { h->opt_lookahead = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "pan_priority")) {
@@ -1891,6 +1910,101 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
     grad[0] = scale1 * (0.5 * Td - Qd / (2.0 * sf));
     grad[1] = snt * (0.5 * trKinv - aa / (2.0 * sf));
   }
+  return SIGP_OK;
+}
+
+// MLII for a lockstep group of RBF / Matern fits on the resident batch data (sigp_batch_upload): value and exact gradient of
+// the profiled nlML (north/June1st.py:235-257 with the true derivative, as sigp_nlml_grad's grad_mode 2) for `count`
+// (data set, theta) pairs -- fit i uses data set (first + i) % batch -- in groups of `group` members that advance through
+// every launch together: covariance build, blocked Cholesky, L~^-T by recursive triangular inversion (grid.z = member),
+// K~^-1 = U U^T (grid.y = member), A~ = U z, and the trace / quadratic-form reductions with dK~/dlog l recomputed on the
+// fly.  This is what a multi-start optimiser over the retrospective years calls once per iteration.
+// nlml [count], grad [count][2] (may be NULL with grad_mode 0); a non-SPD member gets +inf (the reference's except branch).
+int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kernel_id, const double* theta, int grad_mode, double* nlml, double* grad) {
+  if (!h || h->b_count == 0 || first < 0 || count < 1 || !theta || !nlml) return fail(h, SIGP_BAD_ARG, "nlml_grad_batch: bad argument (sigp_batch_upload first)");
+  if (h->dtype != SIGP_F64) return fail(h, SIGP_BAD_ARG, "nlml_grad_batch: fp64 engine only");
+  if (kernel_id != SIGP_KERNEL_RBF && kernel_id != SIGP_KERNEL_MATERN52) return fail(h, SIGP_BAD_ARG, "nlml_grad_batch: RBF / MATERN52 only");
+  if (grad_mode != 0 && grad_mode != 2) return fail(h, SIGP_BAD_ARG, "nlml_grad_batch: grad_mode 0 (value) or 2 (exact gradient)");
+  if (grad_mode != 0 && !grad) return fail(h, SIGP_BAD_ARG, "nlml_grad_batch: grad buffer required");
+  HIPCHK(h, hipSetDevice(h->device));
+  const long n = h->b_n, d = h->b_d, dp = h->b_dp, n_pad = h->b_npad, ld = n_pad;
+  const int T = (int)(n_pad / NB);
+  const int G = (int)std::max<long>(1, std::min<long>(h->opt_group, count));
+  const double inf = std::numeric_limits<double>::infinity();
+  Slot& s = h->slots[0];
+  hipStream_t st = s.s_upd;
+  int rc;
+  if ((rc = slot_reserve(h, s, n_pad, G))) return rc;
+  if (grad_mode != 0) {
+    if ((rc = ensure(h, &h->gU, &h->cap_gU, (long)G * n_pad * n_pad))) return rc;
+    if ((rc = ensure(h, &h->gK, &h->cap_gK, (long)G * n_pad * n_pad))) return rc;
+    if ((rc = ensure(h, &h->gPart, &h->cap_gPart, (long)G * (4 * n_pad + 4)))) return rc;
+    if ((rc = ensure(h, &h->scratchZ, &h->cap_Z, (long)G * n_pad))) return rc;
+  }
+  std::vector<double> sums((size_t)G * 4);
+  for (long g0 = 0; g0 < count; g0 += G) {
+    const int nb = (int)std::min<long>(G, count - g0);
+    std::vector<double> ell((size_t)nb), snt((size_t)nb);
+    std::vector<char> ok((size_t)nb, 1);
+    for (int b = 0; b < nb; ++b) {
+      ell[(size_t)b] = std::exp(theta[2 * (g0 + b)]); snt[(size_t)b] = std::exp(theta[2 * (g0 + b) + 1]);
+      if (!std::isfinite(ell[(size_t)b]) || !std::isfinite(snt[(size_t)b]) || !(ell[(size_t)b] > 0)) { ok[(size_t)b] = 0; ell[(size_t)b] = 1.0; snt[(size_t)b] = 1.0; }
+      s.kps_host[b] = make_kparams(kernel_id, ell[(size_t)b], snt[(size_t)b], (int)((first + g0 + b) % h->b_count));
+    }
+    if ((rc = upload_kparams(h, s, nb))) return rc;
+    if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, 0))) return rc;
+    if ((rc = potrf_slot(h, s, nb, n_pad))) return rc;
+    if ((rc = epilogue_slot(h, s, nb, n, n_pad, 0))) return rc;
+    if (grad_mode != 0) {
+      // U = L~^-T for every member at once, P parks in gK
+      {
+        ProfScope ps(h, st, SIGP_KC_MLII, nb * (double)n_pad * n_pad * n_pad / 3, 0.0);
+        if ((rc = trtri_levels<double>(h, st, s.mat, ld, s.dinv, h->gU, h->gK, ld, T, T, nb, s.matStride, s.dinvStride, n_pad * n_pad))) return rc;
+      }
+      {   // K~^-1 = U U^T, lower tiles
+        ProfScope ps(h, st, SIGP_KC_MLII, nb * (double)n_pad * n_pad * n_pad / 3, 0.0);
+        GemmArgs g{};
+        g.A = h->gU; g.lda = ld; g.B = h->gU; g.ldb = ld; g.C = h->gK; g.ldc = ld; g.K = (int)n_pad;
+        g.batch = nb; g.sA = g.sB = g.sC = n_pad * n_pad;
+        g.r0 = 0; g.r1 = T; g.c0 = 0; g.c1 = T; g.lower = 1; g.ktri = 1;
+        if ((rc = launch_syrk128_t<double, true>(h, st, g))) return rc;
+      }
+      // A~ = U z  (z = solved ride row 0 of each member)
+      hipLaunchKernelGGL(rowdot_kernel<double>, dim3((unsigned)((n_pad + 3) / 4), (unsigned)nb), dim3(256), 0, st, (const double*)h->gU, ld, (int)n_pad, (int)n_pad, 2,
+                         (const double*)(s.mat + n_pad * ld), ld, h->scratchZ, ld, 1, 0, (const double*)nullptr, 0, 0, n_pad * n_pad, s.matStride, n_pad);
+      HIPCHK(h, hipGetLastError());
+      // derivative covariance ids for the on-the-fly dK~/dlog l (same data sets, same length scales); from pageable memory: the
+      // copy call returns once the host buffer has been staged, so the vector may go out of scope
+      std::vector<KParams> dkp((size_t)nb);
+      for (int b = 0; b < nb; ++b) { dkp[(size_t)b] = make_kparams(kernel_id, ell[(size_t)b], snt[(size_t)b], (int)((first + g0 + b) % h->b_count)); dkp[(size_t)b].kernel_id = kernel_id == SIGP_KERNEL_RBF ? KID_RBF_DLOGL : KID_MATERN52_DLOGL; }
+      if (h->cap_gKps < nb) {
+        if (h->gKps) HIPCHK(h, hipFree(h->gKps));
+        h->gKps = nullptr; h->cap_gKps = 0;
+        HIPCHK(h, hipMalloc((void**)&h->gKps, (size_t)G * sizeof(KParams)));
+        h->cap_gKps = G;
+      }
+      HIPCHK(h, hipMemcpyAsync(h->gKps, dkp.data(), (size_t)nb * sizeof(KParams), hipMemcpyHostToDevice, st));
+      double* part = h->gPart;                   // [nb][n_pad][4], then [nb][4]
+      hipLaunchKernelGGL(grad_reduce_cov_kernel, dim3((unsigned)((n + GR_ROWS - 1) / GR_ROWS), (unsigned)nb), dim3(256), 0, st, (const double*)h->gK, n_pad * n_pad, ld,
+                         (const double*)h->scratchZ, n_pad, (const double*)h->bX, n_pad * dp, (int)dp, (int)d, (int)n, (const KParams*)h->gKps, part, 4 * n_pad);
+      hipLaunchKernelGGL(grad_sum_kernel, dim3((unsigned)nb), dim3(256), 0, st, (const double*)part, 4 * n_pad, (int)n, part + (long)G * 4 * n_pad);
+      HIPCHK(h, hipGetLastError());
+      HIPCHK(h, hipMemcpyAsync(sums.data(), part + (long)G * 4 * n_pad, (size_t)nb * 4 * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if ((rc = sync_slot(h, s))) return rc;
+    for (int b = 0; b < nb; ++b) {
+      const long i = g0 + b;
+      double out[4];
+      finish_results(s.res_host + 512 * b, ok[(size_t)b] ? s.info_host[b] : 1, n, 0, snt[(size_t)b], nullptr, out, nullptr, nullptr);
+      nlml[i] = out[1];
+      if (grad_mode == 0) continue;
+      if (!ok[(size_t)b] || s.info_host[b] != 0) { grad[2 * i] = grad[2 * i + 1] = inf; continue; }
+      const double sf = out[0], Td = sums[(size_t)b * 4], Qd = sums[(size_t)b * 4 + 1], trKinv = sums[(size_t)b * 4 + 2], aa = sums[(size_t)b * 4 + 3];
+      grad[2 * i] = 0.5 * Td - Qd / (2.0 * sf);                      // d/dlog l   of the profiled nlML
+      grad[2 * i + 1] = snt[(size_t)b] * (0.5 * trKinv - aa / (2.0 * sf));   // d/dlog sn~
+    }
+  }
+  h->built = h->factored = h->fitted = false;
   return SIGP_OK;
 }
 

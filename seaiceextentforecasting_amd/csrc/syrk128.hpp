@@ -207,11 +207,12 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
       bz = blockIdx.y;
       if (!gemm_tile_coords(g, blockIdx.x, bi, bj)) return;
     }
-    const T* Ag = g.A + bz * g.sA + (long)bi * SY_T * g.lda;
-    const T* Bg = g.B + bz * g.sB + (long)bj * SY_T * g.ldb;
+    const long zz = (long)blockIdx.z;
+    const T* Ag = g.A + bz * g.sA + zz * g.zA + (long)bi * SY_T * g.lda;
+    const T* Bg = g.B + bz * g.sB + zz * g.zB + (long)bj * SY_T * g.ldb;
     int K = g.K;
     if (g.ktri == 1) { const int ks = bi * SY_T; Ag += ks; Bg += ks; K -= ks; }   // upper-triangular operand rows: nothing left of the diagonal block
-    T* Cw = g.C + bz * g.sC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
+    T* Cw = g.C + bz * g.sC + zz * g.zC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long ph0 = 0, ph1 = 0;
@@ -234,6 +235,9 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   }
 }
 
+// The two tile-shape experiments below (128 x 256 and 128 x 64 workgroup tiles: bit-identical results, both measured slower,
+// DESIGN.md section 7) are compiled into libsigp_debug.so only.
+#ifdef SIGP_DEBUG_TOOLS
 // ---- 128 x 256 workgroup tile (8 waves) -------------------------------------------------------------------------------------
 // The same update, C[128 x 256] -= A[128 x K] B[256 x K]^T, by 8 waves (2 x 4 quadrants of 64 x 64): one A slice serves two
 // 128-column blocks, so a K-slice moves 48 KiB global -> LDS for two tiles instead of 64 KiB (6 instead of 8 DMA instructions per
@@ -461,6 +465,8 @@ __global__ __launch_bounds__(256, 3) void syrk_n64_kernel(GemmArgsT<T> g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * g.ldc + j * 16 + lr] = -acc[i][j][r];
 }
+
+#endif  // SIGP_DEBUG_TOOLS
 
 // Panel solve by row strips (panel_mode 1).  The top Wp x Wp block of a panel is already factored and
 //   Mt = [ inv(L_00)                                   ]      (block row j: -inv(L_jj) L_jk for k < j, inv(L_jj) at k = j)

@@ -28,7 +28,7 @@ class LinAlgError(np.linalg.LinAlgError):
 
 
 class GPR:
-    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, reserve_cus=None, schedule=None,
+    def __init__(self, kernel="netdiffusion", dtype="f64", device=0, outer_blocks=None, lookahead=None, schedule=None,
                  panel_mode=None, expm="pade"):
         if kernel not in L.KERNEL_IDS:
             raise ValueError("kernel must be one of %s" % sorted(L.KERNEL_IDS))
@@ -58,8 +58,6 @@ class GPR:
             self.set_option("outer_blocks", outer_blocks)
         if lookahead is not None:
             self.set_option("lookahead", int(bool(lookahead)))
-        if reserve_cus is not None:
-            self.set_option("reserve_cus", reserve_cus)
         if schedule is not None:      # "right" | "left": outer schedule of the blocked Cholesky (same factor, bit for bit)
             self.set_option("schedule", {"right": 0, "left": 1}[schedule])
         if panel_mode is not None:    # "recursive" | "strips" | "auto": how the rows below a panel's top block are solved
@@ -435,6 +433,85 @@ class GPR:
         self._fitted = False
         return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
                     mean=mean[:, :mdim], var=var[:, :mdim])
+
+    def nlml_batch(self, theta, first=0, grad="exact", group=8):
+        """``MLII`` for many (data set, theta) pairs in lockstep on the data sets staged by ``upload_batch`` / ``fit_batch``
+        (RBF / Matern): theta [F, 2] = (log l, log sn~), pair i uses data set (first + i) % B.  Returns (nlml [F], grad [F, 2]
+        or None): the exact derivative of the profiled nlML (north/June1st.py:235-257 with the true gradient), +inf where K~
+        is not SPD.  One device call: this is what an optimiser over all retrospective years evaluates per iteration."""
+        if self.kernel == "netdiffusion":
+            raise ValueError("nlml_batch covers the RBF / Matern kernels (the reference kernel at reference size: nlml_grid / SmallBatch)")
+        if grad not in (None, "exact"):
+            raise ValueError("grad must be None or 'exact'")
+        theta = L.f64(np.atleast_2d(theta), 2)
+        if theta.shape[1] != 2:
+            raise ValueError("theta must be [F, 2]")
+        F = theta.shape[0]
+        self.set_option("group", group)
+        val = np.zeros(F)
+        g = np.zeros((F, 2))
+        self._check(self._lib.sigp_nlml_grad_batch(self._h, int(first), F, self._kid, L.ptr(theta), 0 if grad is None else 2, L.ptr(val),
+                                                   L.ptr(g) if grad is not None else None), "nlml_batch")
+        self._fitted = False
+        return val, (g if grad is not None else None)
+
+    def optimize_batch(self, X, y, theta0, group=8, maxiter=50, gtol=1e-5, ftol=1e-10, max_step=2.0):
+        """The reference's commented-out ``minimize(MLII, x0, method='CG', jac=True)`` (north/June1st.py:259-262) for EVERY data set
+        of a retrospective run at once: X [B, n, d], y [B, n], theta0 [B, 2] (or [2]) -> dict(x [B, 2], fun [B], nit [B],
+        converged [B], nfev = device calls).  BFGS on the 2-vector (log l, log sn~) per data set, Armijo backtracking; the state of
+        every data set lives on the host and each round evaluates ONE trial point per unfinished data set in a single lockstep
+        device call (``nlml_batch``): the years advance together whatever their individual line searches do."""
+        X = L.f64(X, 3)
+        B = X.shape[0]
+        self.upload_batch(X, y, None, group=group, concurrency=1)
+        th = np.broadcast_to(np.asarray(theta0, dtype=np.float64), (B, 2)).copy()
+        f, g = self.nlml_batch(th, grad="exact", group=group)
+        nfev = 1
+        H = np.tile(np.eye(2), (B, 1, 1))
+        done = ~np.isfinite(f)
+        nit = np.zeros(B, dtype=np.int64)
+        step = np.ones(B)
+        direction = np.zeros((B, 2))
+        trial = th.copy()
+        new_dir = np.ones(B, dtype=bool)
+        for _ in range(maxiter * 8):
+            act = np.flatnonzero(~done)
+            if act.size == 0:
+                break
+            for b in act:
+                if new_dir[b]:
+                    p = -H[b] @ g[b]
+                    if p @ g[b] >= 0:                     # not a descent direction: reset the inverse Hessian
+                        H[b] = np.eye(2); p = -g[b]
+                    nrm = np.linalg.norm(p)
+                    if nrm > max_step:                    # log-space steps of at most max_step
+                        p *= max_step / nrm
+                    direction[b] = p; step[b] = 1.0; new_dir[b] = False
+                trial[b] = th[b] + step[b] * direction[b]
+            trial[done] = th[done]                         # finished data sets ride along at their optimum: one lockstep call per round
+            fa, ga = self.nlml_batch(trial, grad="exact", group=group)
+            ft, gt = fa[act], ga[act]
+            nfev += 1
+            for k, b in enumerate(act):
+                slope = g[b] @ direction[b]
+                if np.isfinite(ft[k]) and ft[k] <= f[b] + 1e-4 * step[b] * slope:
+                    s_ = trial[b] - th[b]; yv = gt[k] - g[b]
+                    df = f[b] - ft[k]
+                    th[b], f[b], g[b] = trial[b].copy(), ft[k], gt[k]
+                    nit[b] += 1
+                    sy = s_ @ yv
+                    if sy > 1e-12:
+                        rho = 1.0 / sy
+                        V = np.eye(2) - rho * np.outer(s_, yv)
+                        H[b] = V @ H[b] @ V.T + rho * np.outer(s_, s_)
+                    new_dir[b] = True
+                    if np.max(np.abs(g[b])) <= gtol or df <= ftol * max(1.0, abs(f[b])) or nit[b] >= maxiter:
+                        done[b] = True
+                else:
+                    step[b] *= 0.5
+                    if step[b] < 1e-8:
+                        done[b] = True
+        return dict(x=th, fun=f, nit=nit, nfev=nfev, converged=np.array([np.isfinite(f[b]) and np.max(np.abs(g[b])) <= max(gtol, 1e-3 * max(1.0, abs(f[b]))) for b in range(B)]), jac=g)
 
     def nlml_grid(self, X, y, ells, sns, concurrency=2, group=8, M=None):
         """nlML on the (l, sn~) grid for one data set -- the offline 20x20 search implied by

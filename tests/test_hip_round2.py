@@ -309,29 +309,72 @@ def test_mlii_gradient_at_multi_block_sizes(S, kind, n, d):
     assert rel(mu, ref["fmean"]) <= TOL_PRED and rel(var, ref["fvar"]) <= max(TOL_PRED, 1e-6 * float(np.exp(th[1])))
 
 
-@pytest.mark.parametrize("opt,val", [("xcd_chunks", 8), ("xcd_chunks", 5), ("update_wgs", 1), ("update_wgs", 37), ("wide_tiles", 1), ("n64_tiles", 1)])
-def test_tile_walk_options_only_move_tiles(S, opt, val):
-    """The XCD-chunked walk and the persistent-grid walk of the trailing update place tiles on different workgroups and
-    nothing else: factor and results bit-identical to the default walk, single fit (two streams) and lockstep batch."""
-    X, y, Xs = O.synthetic_problem(4100, 8, 5, m=1)
-    Ls = []
-    for v in (0, val):
-        with S.GPR(kernel="rbf", outer_blocks=2) as gp:
-            gp.set_option("small_tile_threshold", 0)          # every update through the LDS-DMA kernel, however few tiles
-            gp.set_option(opt, v)
-            gp.fit(X, y, np.sqrt(8.0), 1e-2, Xs=Xs)
-            Ls.append((gp.L_tilde_, gp.nlml_))
-    assert np.array_equal(Ls[0][0], Ls[1][0]) and Ls[0][1] == Ls[1][1]
-    n, d, B = 2100, 8, 10
-    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("kind,n,d,B", [("rbf", 1500, 8, 5), ("matern52", 1100, 5, 3), ("rbf", 4096, 8, 4), ("rbf", 300, 3, 7)])
+def test_lockstep_mlii_gradients_match_the_oracle_for_every_member(S, kind, n, d, B):
+    """sigp_nlml_grad_batch: value and exact gradient of the profiled nlML (north/June1st.py:235-257 with the true derivative) for a
+    lockstep group -- every member against oracle.mlii(grad='exact'), against the single-fit entry point, with ragged group tails
+    and a non-SPD member isolated."""
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n))
     for b in range(B):
-        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 70 + b, m=1)
-    res = []
-    for v in (0, val):
-        with S.GPR(kernel="rbf", outer_blocks=4) as gp:
-            gp.set_option(opt, v)
-            res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
-    assert all(np.array_equal(res[0][k], res[1][k]) for k in ("nlml", "mean", "var", "sigma_f"))
+        Xb[b], yb[b], _ = O.synthetic_problem(n, d, 900 + 17 * b + n, m=1)
+    rng = np.random.default_rng(n)
+    theta = np.column_stack([np.log(np.sqrt(d)) + 0.3 * rng.standard_normal(B), np.log(1e-2) + 0.5 * rng.standard_normal(B)])
+    with S.GPR(kernel=kind) as gp:
+        gp.upload_batch(Xb, yb, None, group=3, concurrency=1)
+        for group in (3, B):                               # a ragged last group, and all members in one
+            val, g = gp.nlml_batch(theta, grad="exact", group=group)
+            for b in range(B if n <= 1500 else 2):
+                rv, rg = O.mlii(theta[b], Xb[b], yb[b], kind=kind, grad="exact")
+                assert abs(val[b] - rv) <= 1e-9 * abs(rv), (b, val[b], rv)
+                assert np.max(np.abs(g[b] - rg)) <= 1e-6 * max(1.0, np.max(np.abs(rg))), (b, g[b], rg)
+        v0, _ = gp.nlml_batch(theta, grad=None, group=B)
+        assert np.array_equal(v0, val)                     # value-only mode: the same factorisation
+        gp.set_data(Xb[1], yb[1])
+        v1, g1 = gp.nlml(theta[1], grad="exact")           # the single-fit entry point on member 1
+        assert abs(v1 - val[1]) <= 1e-12 * abs(v1) and np.max(np.abs(g1 - g[1])) <= 1e-8 * max(1.0, np.max(np.abs(g1)))
+        # a member whose K~ is not SPD (duplicated rows, sn~ -> 0) is isolated: +inf for it, finite for the others
+        Xbad = Xb.copy(); Xbad[1, 40:60] = Xbad[1, 100:120]
+        gp.upload_batch(Xbad, yb, None, group=B, concurrency=1)
+        tb = theta.copy(); tb[1, 1] = -80.0
+        val, g = gp.nlml_batch(tb, grad="exact", group=B)
+        assert np.isinf(val[1]) and np.all(np.isinf(g[1])) and np.all(np.isfinite(np.delete(val, 1))) and np.all(np.isfinite(np.delete(g, 1, axis=0)))
+
+
+@pytest.mark.timeout(900)
+def test_batched_multi_start_optimiser_over_the_years(S):
+    """GPR.optimize_batch: BFGS on (log l, log sn~) for every data set at once, one lockstep device call per round -- reaches the
+    optimum scipy's L-BFGS-B finds for each data set through the single-fit MLII, in far fewer device calls than the sum of theirs."""
+    B, n, d = 6, 700, 4
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n))
+    for b in range(B):
+        Xb[b], yb[b], _ = O.synthetic_problem(n, d, 3100 + b, m=1)
+    th0 = np.log([np.sqrt(d), 1e-1])
+    with S.GPR(kernel="rbf") as gp:
+        r = gp.optimize_batch(Xb, yb, th0, group=B, maxiter=40)
+        assert np.all(r["converged"]), r
+        calls = 0
+        for b in range(B):
+            gp.set_data(Xb[b], yb[b])
+            ref = gp.optimize(th0, method="L-BFGS-B")
+            calls += ref.nfev
+            assert r["fun"][b] <= ref.fun + 1e-6 * abs(ref.fun), (b, r["fun"][b], ref.fun)
+            assert np.max(np.abs(r["x"][b] - ref.x)) <= 5e-3, (b, r["x"][b], ref.x)
+            # the optimum is a stationary point of the ORACLE's profiled nlML as well
+            _, og = O.mlii(r["x"][b], Xb[b], yb[b], kind="rbf", grad="exact")
+            assert np.max(np.abs(og)) <= 1e-2 * max(1.0, abs(r["fun"][b]) * 1e-3), (b, og)
+        assert r["nfev"] < calls
+
+
+def test_rejected_experiments_are_not_in_the_product_library(S):
+    """The tile-walk / tile-shape experiments of DESIGN.md section 7 (all measured slower) live in libsigp_debug.so only: the product
+    library refuses their switches (tools/tile_opt_check.py checks their bit-identity against the debug library)."""
+    with S.GPR(kernel="rbf") as gp:
+        for name in ("xcd_chunks", "update_wgs", "update_late", "pipeline_head", "wide_tiles", "n64_tiles", "patch", "small_nt64", "reserve_cus", "panel_ll"):
+            with pytest.raises(ValueError, match="libsigp_debug"):
+                gp.set_option(name, 1)
+        for name, v in (("outer_blocks", 4), ("lookahead", 1), ("panel_chain", 3), ("first_on_panel", 1), ("strips_after_update", 0), ("schedule", 0)):
+            gp.set_option(name, v)
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
