@@ -301,6 +301,15 @@ class Network:
             cov = np.atleast_2d(np.cov(series, bias=True))
         else:
             cov = np.zeros((len(ids), len(ids)))
+        # the reference forms a link as pearsonr(a, b)[0] * sd_a * sd_b (ComplexNetworks.py:311-318: stats.pearsonr x sdA x sdA2): for an area whose series is
+        # constant that is NaN (0/0 inside pearsonr), which nansum then ignores in the strength; keep the NaN so that ``links``
+        # itself is the reference's output too
+        sd = np.std(series, axis=1)
+        const = sd == 0.0
+        if np.any(const) and len(ids) > 1:
+            cov = cov.copy()
+            cov[const, :] = np.nan
+            cov[:, const] = np.nan
         np.fill_diagonal(cov, 0.0)
         self.links = {A: [0 if j == row else cov[row, j] for j in range(len(ids))] for row, A in enumerate(ids)}
         self.strength = {A: np.nansum(np.abs(cov[row])) for row, A in enumerate(ids)}
