@@ -79,6 +79,7 @@ def load(debug=False):
     ``debug=True`` (tools/ only) loads libsigp_debug.so instead: the same library plus the micro-benchmark entry
     points of include/sigp_debug.h; the product package never asks for it."""
     global _lib, _dbg
+    debug = debug or os.environ.get("SIGP_USE_DEBUG_LIB") == "1"      # tools/ only: measurement switches through the ordinary GPR class
     if debug and _dbg is not None:
         return _dbg
     if not debug and _lib is not None:
