@@ -30,7 +30,10 @@ import time
 
 import numpy as np
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # one hardware queue per HIP stream (panel / update streams overlap)
+# one hardware queue per HIP stream (panel / update / communication streams overlap).  Multi-rank runs also hold two RCCL communicators
+# (torch's and the library's), each with a dozen streams of its own: more queues, so that none of them shares one with the library's streams
+_USER_HW_QUEUES = os.environ.get("GPU_MAX_HW_QUEUES")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "16")
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -85,6 +88,8 @@ def spawn_ranks(args):
     env = dict(os.environ)
     env["SIGP_BENCH_ARGV"] = json.dumps(sys.argv[1:])     # torchrun's own argparse would claim abbreviations such as --n / --d
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC (RCCL needs it)
+    if _USER_HW_QUEUES is None:
+        env["GPU_MAX_HW_QUEUES"] = "32"                   # (see the top of this file)
     raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
