@@ -43,6 +43,12 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
   const int wm = wave >> 1, wn = wave & 1;
   const int lr = lane & 15, lq = lane >> 4;
+  // fp32: the MFMA is issued with its operands swapped, D' = B_j A_i^T = (A_i B_j^T)^T, so that a lane's four accumulator registers are
+  // four CONSECUTIVE COLUMNS of one row of C (row lr, columns 4 lq .. 4 lq + 3: v_mfma_f32_16x16x4_f32 puts row 4 lq + r, column lr of
+  // ITS product in register r) -- one 16-byte load and one 16-byte store per accumulator instead of four 4-byte ones (a quarter of the
+  // vector-memory instructions of the prologue and the epilogue, which are issue-bound).  The products and their order are the same:
+  // results are bit-identical to the untransposed form.  (fp64 puts rows lq + 4 r in a lane: nothing contiguous either way.)
+  constexpr bool TRANSPOSED_ACC = sizeof(T) == 4;
 
   acc_t acc[4][4];
   if (SET || (dbg & 8)) {
@@ -52,6 +58,15 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = (T)0;
+  } else if (TRANSPOSED_ACC) {   // fp32: one 16-byte load per accumulator (see TRANSPOSED_ACC below)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const acc_t c = *(const acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * 16 + 4 * lq);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = -c[r];
+      }
   } else if (!(dbg & 128)) {   // accumulator-layout loads straight from global: 64 8-byte loads per lane
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -145,7 +160,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
     if (dbg & 64) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_sched_barrier(0);
     if (!(dbg & 4)) __syncthreads();
@@ -165,7 +180,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef SY_ISSUE
@@ -175,9 +190,17 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        if (TRANSPOSED_ACC) {
+          acc_t c;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+          for (int r = 0; r < 4; ++r) c[r] = SET ? acc[i][j][r] : -acc[i][j][r];
+          *(acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * 16 + 4 * lq) = c;
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+        }
+      }
   }
 }
 

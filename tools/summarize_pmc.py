@@ -1,10 +1,13 @@
 """Summarise the rocprofv3 --pmc passes of tools/collect_profiles.sh into profiles/<round>_pmc_syrk128.json."""
-import json, sys
+import json, os, sys
 import pandas as pd
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = "gpurun_out/%s/" % rnd
 out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile  (one pass per counter set)",
-       "kernel": "sigp::syrk128_kernel<double, false, false>", "notes": []}
+       "kernel": "sigp::syrk128_kernel<double, false, false>", "notes": [],
+       "kernel_code_sha16": bench.kernel_code_sha16()}      # bench.py quotes roofline.traffic from this file only while the kernel code is the same
 sel = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<double, false", regex=False)]   # the trailing / inner updates (not the SET = true panel solve)
 fe = sel(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
 wr = sel(pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv"))
@@ -41,3 +44,28 @@ kb["hbm_total_GBps"] = (kb["write_bytes_per_launch"] + kb["fetch_bytes_per_launc
 kb["frac_of_8TBps"] = kb["hbm_total_GBps"] / 8000.0
 json.dump(kb, open("profiles/%s_pmc_kbuild.json" % rnd, "w"), indent=1)
 print("kbuild: write GB %.2f fetch GB %.2f in %.3f ms -> %.2f TB/s" % (kb["write_bytes_per_launch"] / 1e9, kb["fetch_bytes_per_launch_corrected"] / 1e9, kb["rocprofv3_stats_avg_ms"], kb["hbm_total_GBps"] / 1e3))
+
+# the fp32 trailing update at configs[4]'s shape (one fit, n = 32768, d = 32): tools/collect_profiles.sh <round> f32
+try:
+    self = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<float, false", regex=False)]
+    ff = self(pd.read_csv(base + "f32_pmc_FETCH_SIZE/f32_counter_collection.csv"))
+    fw = self(pd.read_csv(base + "f32_pmc_WRITE_SIZE/f32_counter_collection.csv"))
+    fs = pd.read_csv(base + "f32_stats/f32_kernel_stats.csv")
+    fs = fs[fs["Name"].str.contains("syrk128_kernel<float, false", regex=False)]
+    n = 32768
+    f32 = {"kernel": "sigp::syrk128_kernel<float, false, false> (trailing + in-panel updates of one fp32 Cholesky, n = 32768, outer panels of 8 x 128)",
+           "command": "rocprofv3 --pmc <C> / --kernel-trace --stats -- python3 tools/shard_profile.py --single --dtype f32 --n 32768 --d 32 --kernel matern52 --sn 0.1 --reps 2",
+           "launches_per_run": int(len(ff)), "fetch_bytes_total_corrected": float(ff["Counter_Value"].sum()) * 1024 * 2, "write_bytes_total": float(fw["Counter_Value"].sum()) * 1024,
+           "stats_total_ms": float(fs["TotalDurationNs"].iloc[0]) / 1e6, "stats_calls": int(fs["Calls"].iloc[0]), "fits_in_run": 3,
+           "algorithmic_flops_per_fit": n ** 3 / 3.0}
+    f32["tflops_in_kernel"] = f32["algorithmic_flops_per_fit"] * f32["fits_in_run"] / (f32["stats_total_ms"] * 1e-3) / 1e12
+    f32["frac_of_fp32_mfma_peak"] = f32["tflops_in_kernel"] / 157.3
+    try:
+        fm = self(pd.read_csv(base + "f32_pmc_mfma/f32_counter_collection.csv")).groupby("Counter_Name")["Counter_Value"].sum()
+        f32["mfma_pipe_busy_fraction"] = float(fm["SQ_VALU_MFMA_BUSY_CYCLES"] / (fm["GRBM_GUI_ACTIVE"] / 8 * 1024))
+    except Exception:
+        pass
+    json.dump(f32, open("profiles/%s_pmc_syrk128_f32.json" % rnd, "w"), indent=1)
+    print("syrk128<float>: %.1f TFLOP/s in-kernel (%.2f of peak), fetch %.1f GB, write %.1f GB per run" % (f32["tflops_in_kernel"], f32["frac_of_fp32_mfma_peak"], f32["fetch_bytes_total_corrected"] / 1e9, f32["write_bytes_total"] / 1e9))
+except FileNotFoundError as e:
+    print("no fp32 passes:", e)
