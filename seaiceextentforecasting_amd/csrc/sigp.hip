@@ -132,6 +132,7 @@ struct sigp_handle {
     float* Uinv = nullptr; float* Vinv = nullptr; size_t cap_inv = 0;        // [own panel][PW][PW] each (upper: L_pp^-T, lower: L_pp^-1)
     float* invP = nullptr; size_t cap_invP = 0;                              // scratch of one inversion
     float* ft = nullptr; float* fx = nullptr; float* fr = nullptr; float* fc = nullptr; size_t cap_vec = 0; size_t cap_ft = 0;
+    long cap_ref_npad = 0;                     // order the fp64 refinement vectors (xq, rq, rpart, fpart) of a sharded fp32 fit are sized for
     double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
