@@ -40,6 +40,8 @@ def run(cases, seed, verbose=True):
           e = float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)))
           if dtype == "f64":
               worst[k] = max(worst[k], e)
+          if k == "nlml" and dtype == "f32":      # the fp32 factor's log-determinant: an absolute error of ~1e-7 per order, whatever nlML's own size
+              e = min(e, float(np.max(np.abs(a - b))) / (1e-6 * max(n, 1)) * tol[k])
           if not (e <= tol[k]):
               fails += 1
               print("FAIL case %d: n=%d d=%d m=%d %s %s W=%d %s : %s rel err %.3e" % (case, n, d, m, kind, dtype, W, opts, k, e), flush=True)

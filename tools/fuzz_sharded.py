@@ -38,7 +38,7 @@ for case in range(cases):
         if m:
             got["mean"], got["var"] = dg.predict(Xs)
         if dtype == "f32":
-            assert 0 < dg.refine_residual_ <= 1e-9, (case, dg.refine_residual_)
+            assert (0 < dg.refine_residual_ or n <= 4) and dg.refine_residual_ <= 1e-9, (case, n, dg.refine_residual_)   # (orders 1-4 can be solved exactly)
     tol = {"mean": 1e-8, "var": 1e-8, "nlml": 1e-9, "sigma_f": 1e-8} if dtype == "f64" else {"mean": 1e-6, "var": 1e-5, "nlml": 5e-5, "sigma_f": 1e-6}
     refd = {"mean": ref["fmean"][:m], "var": ref["fvar"][:m], "nlml": ref["nlml"], "sigma_f": ref["sigma_f"]}
     for k in got:
