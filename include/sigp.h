@@ -192,8 +192,8 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
 /* One large fit sharded over the GPUs of a node (BASELINE configs[3] fp64, configs[4] fp32 + fp64 refinement): 1-D block-cyclic
  * ownership of outer panels (W column blocks of 128; panel q belongs to rank q % nranks), OWNER-ONLY storage -- a rank allocates,
  * builds and updates only the block columns of its own panels (per-rank matrix bytes ~ 1/nranks) -- and the block-row panel
- * broadcast inside the library: per panel the owner factors it on its panel stream, packs [rows from its diagonal block down,
- * ride rows included] x [its columns] into a contiguous device buffer, the buffer is broadcast on a communication stream (RCCL over
+ * broadcast inside the library: per panel the owner factors it on its panel stream, packs [rows below its top block, ride rows
+ * included] x [its columns] into a contiguous device buffer (what the later panels read; the last panel does not travel), the buffer is broadcast on a communication stream (RCCL over
  * xGMI) while every rank is still applying the previous panel (look-ahead), and every rank updates its own later panels straight
  * out of the buffer.  Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the
  * pivot info is MIN-reduced once at the end together with the 512 partial ride-row reductions (the only other fp64 exchange).

@@ -639,7 +639,7 @@ for la in (True, False):
         st = dg.stats()
         nl = dg.nlml_
     assert relf(mu, ref["fmean"]) <= 1e-8 and relf(var, ref["fvar"]) <= 1e-8 and relf(nl, ref["nlml"]) <= 1e-9
-    assert st["collectives"] >= 5 + 2 and st["bcast_bytes"] > 0, st          # 5 panels + the two all-reduces went through RCCL
+    assert st["collectives"] >= 4 + 2 and st["bcast_bytes"] > 0, st          # 5 panels (the last one has no reader and stays home) + the two all-reduces went through RCCL
 Xf, yf, Xsf = O.synthetic_problem(900, 16, 515, m=2)
 reff = O.fit_predict(Xf, yf, Xsf, 4.0, 1e-1, kind="matern52", ref_idiom=False)
 with S.DistributedGPR("matern52", rank, world, dist, device=0, outer_blocks=2, dtype="f32", force_rccl=True) as dg:

@@ -97,7 +97,7 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
             if world > 1 and T >= 4 * W:
                 assert dg.matrix_bytes_ <= 0.75 * one[2], (dg.matrix_bytes_, one[2])
             st = dg.stats()
-            assert st["fit_ms"] > 0 and (world == 1 or st["bcast_bytes"] > 0), st
+            assert st["fit_ms"] > 0 and (world == 1 or P == 1 or st["bcast_bytes"] > 0), st      # (the last panel has no reader: it does not travel)
             try:
                 dg.predict(Xs + 1.0)
                 raise SystemExit("expected RuntimeError")
@@ -191,7 +191,7 @@ for dtype, tol in (("f64", 1e-8), ("f32", 1e-6)):
         else:
             r32 = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-1, kind="rbf", ref_idiom=False)
             assert rel(mu, r32["fmean"]) <= tol and rel(var, r32["fvar"]) <= 1e-5 and 0 < resid <= 1e-10
-        assert st["collectives"] >= 7 + 2 and st["bcast_bytes"] > 0 and st["comm_ms"] > 0, st
+        assert st["collectives"] >= 6 + 2 and st["bcast_bytes"] > 0 and st["comm_ms"] > 0, st      # 7 panels: 6 travel, + the two all-reduces
 # the rendezvous channel that needs no torch
 from seaiceextentforecasting_amd.dist import tcp_exchange_id
 with S.DistributedGPR("rbf", 0, 1, None, device=0, force_rccl=True) as dg:
