@@ -421,9 +421,9 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
              "ms_per_fit": 1e3 * best, "ms_per_fit_all": [round(1e3 * t, 3) for t in times], "fits_per_s": 1.0 / best,
              "tflops": flops_per_fit(n, d) / best / 1e12, "frac_of_peak_all_gpus": flops_per_fit(n, d) / best / 1e12 / (peak * world),
              "panel_broadcast_bytes_per_fit": st["bcast_bytes"], "collectives_per_fit": st["collectives"],
-             "max_over_ranks_ms": {"update_stream_stalled_on_a_panel": float(vmax[0]), "broadcasts_in_flight": float(vmax[1]), "panel_loop_device_time": float(vmax[2]),
+             "max_over_ranks_ms": {"update_stream_stalled_on_a_panel": float(vmax[0]), "communication_window_first_segment_ready_to_last_arrived": float(vmax[1]), "panel_loop_device_time": float(vmax[2]),
                                    "reductions_solves_refinement_host_time": float(vmax[3])},
-             "broadcast_hidden_by_lookahead": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
+             "share_of_communication_window_with_update_work": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
              "matrix_bytes_max_rank": float(vmax[4]), "sigma_f": res["sigma_f"], "nlml": res["nlml"], "mean": res["mean"], "var": res["var"]}
         if "refinement_residual" in res:
             e["refinement_residual"] = res["refinement_residual"]

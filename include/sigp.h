@@ -193,9 +193,10 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
  * ownership of outer panels (W column blocks of 128; panel q belongs to rank q % nranks), OWNER-ONLY storage -- a rank allocates,
  * builds and updates only the block columns of its own panels (per-rank matrix bytes ~ 1/nranks) -- and the block-row panel
  * broadcast inside the library: per panel the owner factors it on its panel stream, packs [rows below its top block, ride rows
- * included] x [its columns] into a contiguous device buffer (what the later panels read; the last panel does not travel), the buffer is broadcast on a communication stream (RCCL over
- * xGMI) while every rank is still applying the previous panel (look-ahead), and every rank updates its own later panels straight
- * out of the buffer.  Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the
+ * included] x [its columns] (what the later panels read; the last panel does not travel) in SEGMENTS of `dist_segment` column blocks:
+ * a segment is broadcast on a communication stream (RCCL over xGMI) as soon as its last column is solved, while the owner's chain
+ * goes on with the next columns and every rank is still applying the previous panel (look-ahead); the next panel's owner applies
+ * each segment to its columns as it arrives, every other rank assembles the segments and updates its later panels in one launch.  Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the
  * pivot info is MIN-reduced once at the end together with the 512 partial ride-row reductions (the only other fp64 exchange).
  * Replaces north/June1st.py:265 (np.linalg.cholesky) and :266-277, :246 for one large K~, as sigp_fit_predict does on one GPU.
  * fp32 handles (SIGP_F32): the fp32 factor is sharded the same way; x = K~^-1 [y k*] then comes from triangular solves on the
@@ -253,7 +254,8 @@ int sigp_profile_reset(sigp_handle* h);
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
- *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit
+ *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
+ *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:
  *   the trailing-update kernel's own rate, bench.py's roofline.unshared)
  *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [3] (bit 0: panels that are not strip-solved,

@@ -125,7 +125,9 @@ struct sigp_handle {
     sigp_transport tr{};
     hipStream_t s_comm = nullptr;              // the panel broadcasts run here, beside the update and panel streams
     void* hstage = nullptr; size_t cap_hstage = 0;   // pinned staging buffer of a host-pointer transport
-    void* pbuf[2] = {nullptr, nullptr}; size_t cap_pbuf = 0;   // two packed-panel buffers in rotation (device)
+    void* pbuf[2] = {nullptr, nullptr}; size_t cap_pbuf = 0;   // two row-major panel buffers in rotation (device)
+    void* sbuf[2] = {nullptr, nullptr};                        // ... and two staging buffers of the streamed segments (same size)
+    hipEvent_t ev_seg = nullptr;                               // a segment has arrived (next owner's panel stream waits for it)
     hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_first[2] = {nullptr, nullptr}, ev_mark = nullptr;
     std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
     // sharded triangular solves of the fp32 refinement: inverses of the own panels' diagonal blocks, panel-major work vectors
@@ -138,6 +140,7 @@ struct sigp_handle {
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
     double st_collectives = 0, st_host_comm_ms = 0, st_enqueue_ms = 0;
   } dc;
+  int opt_dist_seg = 2;                        // sharded fit: column blocks per streamed broadcast segment (>= panel width: the panel travels whole)
   int opt_dist_stats = 0;                      // time the broadcasts and the update stream's waits for them with HIP events
   int opt_owner_only = 0;                      // sigp_set_train does not allocate the full n x n slot matrix
   // state
@@ -821,14 +824,16 @@ int dist_update(sigp_handle* h, Real* Mm, hipStream_t st, long n_pad, int kcol0,
 
 // Mm = (virtual) origin of the storage the panel's columns live in, row stride ld: the slot's square matrix (ld = n_pad) or one
 // rank's block columns (sigp_dist_local_*: ld = its column count, origin shifted so that GLOBAL column indices land in it)
+// on_col (may be null): called right after the column solve of block column c has been enqueued -- that column is then final
+// (the sharded fit streams it to the other ranks while the chain goes on)
 template <typename Real>
-int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp);
+int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp, const std::function<int(int)>* on_col = nullptr);
 // the panel in its latency-chain form (potrf_core's panel_chain, one member): right-looking column by column, the update of the
 // columns beyond the next one riding in the next diagonal block's launch.  Same k order per tile as the recursion: bit-identical.
 template <typename Real>
-int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
+int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp, const std::function<int(int)>* on_col = nullptr) {
   const int T = (int)(n_pad / NB), R = T + 1;
-  if (!(h->opt_panel_chain & 1) || Wp <= 2 || (long)(R - J0) > h->opt_chain_rows) return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, Wp);
+  if (!(h->opt_panel_chain & 1) || Wp <= 2 || (long)(R - J0) > h->opt_chain_rows) return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, Wp, on_col);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());
   static AttrOnce du_attr, d_attr;
@@ -876,6 +881,7 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStrea
         if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g))) return rc;
       }
     }
+    if (on_col && (rc = (*on_col)(c))) return rc;
     if (i + 1 >= Wp) break;
     if ((rc = gemm_sub_auto(h, sp, upd_args(c, c + 1, 0, 1)))) return rc;
     const int rest = Wp - i - 2;
@@ -892,7 +898,7 @@ int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStrea
 }
 
 template <typename Real>
-int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp) {
+int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp, const std::function<int(int)>* on_col) {
   const int T = (int)(n_pad / NB), R = T + 1;
   if (Wp == 1) {
     const int c = J0;
@@ -906,12 +912,14 @@ int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipS
     g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
     g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
     g.batch = 1; g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
-    if (rows_below >= h->opt_trsm128) { g.r1 = rows_below; return launch_syrk128_t<Real, true>(h, sp, g); }
-    g.r1 = rows_below * 4;
-    return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+    int rc1;
+    if (rows_below >= h->opt_trsm128) { g.r1 = rows_below; rc1 = launch_syrk128_t<Real, true>(h, sp, g); }
+    else { g.r1 = rows_below * 4; rc1 = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g); }
+    if (rc1) return rc1;
+    return on_col ? (*on_col)(c) : SIGP_OK;
   }
   const int hw = Wp / 2;
-  int rc = dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, hw);
+  int rc = dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, hw, on_col);
   if (rc) return rc;
   {   // columns of the right half -= (left half)(left half)^T, rows from the right half's diagonal block down
     const long o = (long)(J0 + hw) * NB;
@@ -922,7 +930,7 @@ int dist_panel_rec(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipS
     g.batch = 1; g.K = hw * NB; g.r0 = 0; g.r1 = R - (J0 + hw); g.c0 = 0; g.c1 = Wp - hw; g.lower = 1;
     if ((rc = gemm_sub_auto(h, sp, g))) return rc;
   }
-  return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0 + hw, Wp - hw);
+  return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0 + hw, Wp - hw, on_col);
 }
 
 // epilogue reductions on the ride blocks of slot s + async copy of results / info to pinned host memory
@@ -1162,6 +1170,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "small_nt64")) { h->opt_small_nt64 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_stats")) { h->opt_dist_stats = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "dist_segment")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_dist_seg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
   if (!strcmp(name, "syrk_v2")) {   // the generic 128-tile kernel spills 12 B/lane to scratch: never beside a second stream

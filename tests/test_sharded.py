@@ -106,6 +106,14 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
             dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
             assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
     assert np.array_equal(bits[0][0], bits[1][0]) and np.array_equal(bits[0][1], bits[1][1]) and bits[0][2] == bits[1][2], "look-ahead changed the bits"
+    # the streamed broadcast: segments of 1 / 3 column blocks and whole panels -- the next owner then applies K = 128 / 384 / W 128
+    # updates instead of K = 256 ones: same k order per tile, so the same bits
+    for seg in (1, 3, 64):
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=True) as dg:
+            dg.gp.set_option("dist_segment", seg)
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            assert np.array_equal(mu, bits[0][0]) and np.array_equal(var, bits[0][1]) and dg.nlml_ == bits[0][2], (kind, n, W, seg, "segment width changed the bits")
 # configs[4] shape at test size: fp32 factor sharded, triangular solves on the distributed factor, residual sharded by rows
 for kind, n, d, W, m in (("matern52", 900, 16, 2, 2), ("rbf", 2049, 32, 3, 3), ("matern52", 1500, 8, 1, 0), ("rbf", 300, 4, 4, 1)):
     X, y, Xs = O.synthetic_problem(n, d, 515 + n, m=max(m, 1))
