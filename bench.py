@@ -655,9 +655,9 @@ def cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, nsets, r, local):
                            "sample": "%d timed fit(s)%s (the first timed step: data set %d, l=%.4g, sn~=%.3g), n=%d d=%d, oracle ref_idiom=True = the reference's call sequence north/June1st.py:264-277 (%s)"
                                      % (reps, " after 1 warm-up, median" if reps > 1 else ", cold", ds0, ell0, sn0, nb, d, env),
                            "seconds": tc, "protocol_other_sizes": proto}
-    tb, _ = timed(lambda: O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=False), reps, warm=1 if reps > 1 else 0)
+    tb, _ = timed(lambda: O.fit_predict(Xc, yc, Xsc, ell0, sn0, kind="rbf", ref_idiom=False), 1, warm=1 if reps > 1 else 0)
     out["cpu_baseline_best_practice"] = {"value": 1.0 / tb, "unit": "fits/s", "cores": ncpu, "kind": "port", "seconds": tb,
-                                         "sample": "same inputs and repetitions, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)"}
+                                         "sample": "same inputs, 1 timed fit%s, oracle ref_idiom=False (one Cholesky + scipy solve_triangular)" % (" after 1 warm-up" if reps > 1 else ", cold")}
     if nb == n:   # parity of the timed configuration against the CPU path on the same inputs: the timed lockstep batch's own
         # result for that step, and the same fit through the single-fit entry point
         with GPR(kernel="rbf", device=local) as g2:
