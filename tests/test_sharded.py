@@ -278,3 +278,146 @@ def test_config3_n16384_sharded_over_two_ranks(tmp_path):
         t_shard = best(lambda: dg.refit(ell, sn))
     print("n=16384 single-GPU fit %.2f ms, sigp_dist_fit at world=1 %.2f ms (%+.1f %%)" % (1e3 * t_single, 1e3 * t_shard, 100 * (t_shard / t_single - 1)))
     assert t_shard <= 1.10 * t_single, (t_single, t_shard)
+
+
+# ---- the fully asynchronous path with REAL data movement, on one GPU --------------------------------------------------------------
+# The host-pointer transport synchronises per collective and a one-rank RCCL communicator moves nothing, so neither shows whether the
+# event choreography of the panel loop (segments leaving while the chain runs, buffer rotation, the next owner's segment updates)
+# is right when nothing ever waits on the host.  Here `world` handles live in ONE process, one thread per rank, all on device 0, and
+# the device-pointer transport (sigp_dist_init_transport, device_buffers = 1) is written with HIP events: a broadcast = the root
+# records an event on the library's stream and publishes (pointer, event); every other rank makes ITS stream wait for that event and
+# enqueues a device-to-device copy, then posts a copy-done event the root's stream waits for.  No stream is ever synchronised for a
+# broadcast: what RCCL does between GPUs, between handles.
+_ASYNC_WORKER = r'''
+import ctypes as C, os, sys, threading, time
+sys.path.insert(0, %(root)r)
+import numpy as np
+from oracle import gp_oracle as O
+import seaiceextentforecasting_amd as S
+from seaiceextentforecasting_amd import _lib as L
+lib = L.load()
+hip = C.CDLL("libamdhip64.so.7")                     # the runtime libsigp.so is linked against (already mapped)
+vp = C.c_void_p
+hip.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]; hip.hipEventRecord.argtypes = [vp, vp]
+hip.hipStreamWaitEvent.argtypes = [vp, vp, C.c_uint]; hip.hipMemcpyAsync.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
+hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]; hip.hipStreamSynchronize.argtypes = [vp]
+def chk(rc):
+    if rc != 0:
+        raise RuntimeError("hip error %%d" %% rc)
+
+class Fabric:
+    """what the ranks (threads) share: one slot per collective, matched by its sequence number"""
+    def __init__(self, world):
+        self.world, self.cv, self.slots = world, threading.Condition(), {}
+        self.bar = threading.Barrier(world)
+        self.red = [None] * world
+    def slot(self, seq):
+        with self.cv:
+            return self.slots.setdefault(seq, {"root": None, "done": []})
+
+class Rank:
+    def __init__(self, fab, rank):
+        self.fab, self.rank, self.seq = fab, rank, 0
+        self.events = []
+        self.cb = (L.BCAST_FN(self.bcast), L.ALLREDUCE_FN(self.allreduce))
+        self.tr = L.Transport(None, 1, self.cb[0], self.cb[1])       # device_buffers = 1
+    def event(self, stream):
+        e = vp(); chk(hip.hipEventCreateWithFlags(C.byref(e), 2)); chk(hip.hipEventRecord(e, stream)); self.events.append(e)
+        return e
+    def bcast(self, ctx, buf, nbytes, root, stream):
+        try:
+            fab, sl = self.fab, self.fab.slot(self.seq); self.seq += 1
+            if self.seq %% 3 == self.rank %% 3:                         # uneven progress of the ranks' host threads
+                time.sleep(0.002 * ((self.seq * 7 + self.rank) %% 4))
+            if self.rank == root:
+                ev = self.event(stream)                              # the panel / segment is complete on the library's stream here
+                with fab.cv:
+                    sl["root"] = (buf, ev); fab.cv.notify_all()
+                    fab.cv.wait_for(lambda: len(sl["done"]) == fab.world - 1, timeout=120)
+                    assert len(sl["done"]) == fab.world - 1
+                for d in sl["done"]:
+                    chk(hip.hipStreamWaitEvent(stream, d, 0))        # the buffer may be reused once every copy out of it has run
+            else:
+                with fab.cv:
+                    fab.cv.wait_for(lambda: sl["root"] is not None, timeout=120)
+                    src, ev = sl["root"]
+                chk(hip.hipStreamWaitEvent(stream, ev, 0))
+                chk(hip.hipMemcpyAsync(buf, src, nbytes, 3, stream))  # device to device
+                d = self.event(stream)
+                with fab.cv:
+                    sl["done"].append(d); fab.cv.notify_all()
+            return 0
+        except Exception as e:                                       # must not unwind through the C frames
+            print("bcast callback failed:", repr(e), flush=True); return 1
+    def allreduce(self, ctx, buf, count, is_f32, op, stream):       # a few hundred numbers at the end of a fit: through the host
+        try:
+            fab = self.fab
+            a = np.zeros(count, dtype=np.float32 if is_f32 else np.float64)
+            chk(hip.hipStreamSynchronize(stream)); chk(hip.hipMemcpy(a.ctypes.data, buf, a.nbytes, 2))
+            fab.red[self.rank] = a; fab.bar.wait(timeout=120)
+            parts = [fab.red[r] for r in range(fab.world)]          # summed in rank order on every rank: identical results
+            res = parts[0].copy()
+            for q in parts[1:]:
+                res = res + q if op == 0 else np.minimum(res, q)
+            fab.bar.wait(timeout=120)
+            chk(hip.hipMemcpy(buf, res.ctypes.data, res.nbytes, 1))
+            return 0
+        except Exception as e:
+            print("allreduce callback failed:", repr(e), flush=True); return 1
+
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+world = %(world)d
+cases = [("rbf", "f64", 2100, 8, 2, 3, 1e-2), ("matern52", "f64", 1500, 5, 3, 2, 1e-2), ("rbf", "f64", 6000, 8, 8, 1, 1e-2), ("matern52", "f32", 2049, 16, 2, 2, 1e-1),
+         ("rbf", "f32", 5000, 8, 8, 1, 1e-1), ("rbf", "f64", 300, 3, 4, 1, 1e-2)]
+failures = []
+for kind, dtype, n, d, W, m, sn in cases:
+    X, y, Xs = O.synthetic_problem(n, d, 99 + n, m=m)
+    ell = float(np.sqrt(d))
+    ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+    fab = Fabric(world)
+    out = [None] * world
+    def run(rank):
+        try:
+            rk = Rank(fab, rank)
+            gp = S.GPR(kernel=kind, dtype=dtype)
+            gp.set_option("owner_only", 1)
+            gp._check(lib.sigp_dist_init_transport(gp._h, world, rank, C.byref(rk.tr)), "dist_init_transport")
+            gp.set_data(X, y, Xs=Xs)
+            res = []
+            for rep in range(3):                                      # again and again on the same buffers: rotation and reuse under load
+                o4, mean, var = np.zeros(4), np.zeros(m), np.zeros(m)
+                rc = lib.sigp_dist_fit(gp._h, gp._kid, ell, sn, None, 0, W, 1, L.ptr(o4), L.ptr(mean), L.ptr(var))
+                assert rc == 0, (rc, lib.sigp_last_error(gp._h))
+                res.append((o4.copy(), mean.copy(), var.copy()))
+            out[rank] = res
+            lib.sigp_dist_shutdown(gp._h); gp.close()
+        except BaseException as e:
+            failures.append((kind, dtype, n, rank, repr(e)))
+            try: fab.bar.abort()
+            except Exception: pass
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(300)
+    assert not failures, failures
+    tol = (1e-8, 1e-8, 1e-9) if dtype == "f64" else (1e-6, 1e-5, 1e-5)
+    for rank in range(world):
+        for o4, mean, var in out[rank]:
+            assert rel(mean, ref["fmean"]) <= tol[0] and rel(var, ref["fvar"]) <= tol[1] and rel(o4[1], ref["nlml"]) <= tol[2], (kind, dtype, n, rank, rel(mean, ref["fmean"]), rel(var, ref["fvar"]))
+            assert np.array_equal(mean, out[0][0][1]) and np.array_equal(var, out[0][0][2]) and o4[1] == out[0][0][0][1], (kind, dtype, n, rank, "ranks / repetitions disagree")
+    print("ok", kind, dtype, n, flush=True)
+open(os.path.join(%(out)r, "ok_async"), "w").write("ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fit_fully_asynchronous_device_transport(tmp_path, world):
+    """The panel loop with nothing ever synchronised on the host and REAL data moving between the ranks' buffers: `world` handles in
+    one process (one thread per rank, all on the box's GPU), device-pointer transport written with HIP events.  Three fits in a row
+    per case on the same buffers; every rank and every repetition must give the same bits, == oracle."""
+    script = tmp_path / "worker.py"
+    script.write_text(_ASYNC_WORKER % dict(root=ROOT, out=str(tmp_path), world=world))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=560)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert (tmp_path / "ok_async").exists()
