@@ -406,6 +406,21 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                 if r_ > 0:
                     times.append(float(t.item()))
             st = dg.stats()
+            # A/B for the streamed broadcast: the same fit with whole-panel broadcasts (dist_segment >= W)
+            dg.gp.set_option("dist_segment", 64)
+            whole = []
+            for r_ in range(reps):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                dg.refit(ell, sn)
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if dist is not None:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                whole.append(float(t.item()))
+            dg.gp.set_option("dist_segment", 2)
+            dg.refit(ell, sn)
             mu, var = dg.predict(Xs)
             res = dict(sigma_f=dg.sigma_f_, nlml=dg.nlml_, mean=float(mu[0]), var=float(var[0]), matrix_bytes=dg.matrix_bytes_, transport=dg.transport)
             if dtype == "f32":
@@ -421,6 +436,7 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
              "ms_per_fit": 1e3 * best, "ms_per_fit_all": [round(1e3 * t, 3) for t in times], "fits_per_s": 1.0 / best,
              "tflops": flops_per_fit(n, d) / best / 1e12, "frac_of_peak_all_gpus": flops_per_fit(n, d) / best / 1e12 / (peak * world),
              "panel_broadcast_bytes_per_fit": st["bcast_bytes"], "collectives_per_fit": st["collectives"],
+             "ms_per_fit_with_whole_panel_broadcasts": 1e3 * min(whole), "streamed_segments_gain": min(whole) / best,
              "max_over_ranks_ms": {"update_stream_stalled_on_a_panel": float(vmax[0]), "communication_window_first_segment_ready_to_last_arrived": float(vmax[1]), "panel_loop_device_time": float(vmax[2]),
                                    "reductions_solves_refinement_host_time": float(vmax[3])},
              "share_of_communication_window_with_update_work": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
