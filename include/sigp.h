@@ -196,8 +196,8 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
  * included] x [its columns] (what the later panels read; the last panel does not travel) in SEGMENTS of `dist_segment` column blocks:
  * a segment is broadcast on a communication stream (RCCL over xGMI) as soon as its last column is solved, while the owner's chain
  * goes on with the next columns and every rank is still applying the previous panel (look-ahead); the next panel's owner applies
- * each segment to its columns as it arrives, every other rank assembles the segments and updates its later panels in one launch.  Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the
- * pivot info is MIN-reduced once at the end together with the 512 partial ride-row reductions (the only other fp64 exchange).
+ * each segment to its columns as it arrives, every other rank assembles the segments and updates its later panels in one launch.
+ * Streams are ordered with events only: no host synchronisation and no device-to-host read per panel; the pivot info is MIN-reduced once at the end together with the 512 partial ride-row reductions (the only other fp64 exchange).
  * Replaces north/June1st.py:265 (np.linalg.cholesky) and :266-277, :246 for one large K~, as sigp_fit_predict does on one GPU.
  * fp32 handles (SIGP_F32): the fp32 factor is sharded the same way; x = K~^-1 [y k*] then comes from triangular solves on the
  * DISTRIBUTED factor (per panel: one skinny product with the explicit inverse of the owner's diagonal block + one skinny update
@@ -220,8 +220,10 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
  *                                      The factor stays spread over the ranks: predictions exist for the ride-along points only.
  *   set_option("owner_only", 1) before sigp_set_train keeps an fp64 handle from allocating the n x n single-GPU matrix;
  *   set_option("dist_stats", 1) times the broadcasts with HIP events: sigp_get_stat "dist_fit_ms", "dist_factor_ms" (device time of the
- *   panel loop), "dist_bcast_bytes", "dist_comm_ms" (sum of broadcast intervals on the communication stream), "dist_stall_ms" (time
- *   the update stream sat idle waiting for a panel: what look-ahead did NOT hide), "dist_solve_ms", "dist_collectives". */
+ *   panel loop), "dist_bcast_bytes", "dist_comm_ms" (per panel: first segment ready -> last segment arrived, summed), "dist_stall_ms" (time
+ *   the update stream sat idle waiting for a panel: what look-ahead did NOT hide), "dist_solve_ms", "dist_collectives", "dist_comm_ranks"
+ *   (what the communicator itself reports: ncclCommCount), "dist_host_comm_ms", "dist_enqueue_ms" (host time inside the collectives'
+ *   enqueue calls / for the whole panel loop). */
 typedef struct sigp_transport {
   void* ctx;
   int device_buffers;
