@@ -217,7 +217,7 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
  *   sigp_dist_fit(...)                 after sigp_set_train / sigp_set_test with the SAME data on every rank (n d 8 bytes): the whole
  *                                      sharded fit; out / mean / var as sigp_fit_predict, identical on every rank.  Sigma as there
  *                                      (reference kernel: fp64 only).  SIGP_NOT_SPD + LAPACK pivot in out[2] on every rank otherwise.
- *                                      The factor stays spread over the ranks: predictions exist for the ride-along points only.
+ *                                      The factor stays spread over the ranks; other test points: sigp_dist_predict.
  *   set_option("owner_only", 1) before sigp_set_train keeps an fp64 handle from allocating the n x n single-GPU matrix;
  *   set_option("dist_stats", 1) times the broadcasts with HIP events: sigp_get_stat "dist_fit_ms", "dist_factor_ms" (device time of the
  *   panel loop), "dist_bcast_bytes", "dist_comm_ms" (per panel: first segment ready -> last segment arrived, summed), "dist_stall_ms" (time
@@ -237,6 +237,12 @@ int sigp_dist_init(sigp_handle* h, int nranks, int rank, const void* nccl_id);
 int sigp_dist_init_transport(sigp_handle* h, int nranks, int rank, const sigp_transport* transport);
 int sigp_dist_fit(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma, int64_t W, int lookahead,
                   double* out, double* mean, double* var);
+/* Predictions at NEW test points after a sharded fit (north/June1st.py:272-277): collective -- every rank calls it with the same Xs [m,d]
+ * and gets the same mean / var (var includes sigma_n).  mean = k~*^T alpha~ with alpha~ = K~^-1 y replicated once per fit (fp64: one backward
+ * solve on the distributed factor; fp32: the refined solution); var from forward solves on the distributed factor, 4 points per pass, the
+ * squares summed per rank and all-reduced once.  RBF / Matern fits; fp32 handles: the variance carries the fp32 factor's accuracy
+ * (as sigp_predict on an fp32 handle). */
+int sigp_dist_predict(sigp_handle* h, const double* Xs, int64_t m, int64_t ldxs, double* mean, double* var);
 int sigp_dist_shutdown(sigp_handle* h);                                /* destroy the communicator, free the sharded storage */
 int64_t sigp_num_blocks(sigp_handle* h);                               /* T = n_pad / 128                        */
 

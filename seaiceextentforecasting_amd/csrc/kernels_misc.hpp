@@ -764,22 +764,51 @@ __global__ __launch_bounds__(256) void cross_mean_kernel(const double* __restric
 // pivot info of one rank as a double for the MIN all-reduce over the ranks (0 = none -> a huge value)
 __global__ void info_to_double_kernel(const int* __restrict__ info, double* __restrict__ out) { out[0] = info[0] != 0 ? (double)info[0] : 1e18; }
 
-// ---- panel-major work vectors of the sharded triangular solves (sigp_dist_fit, fp32 engine) ------------------------------
+// ---- panel-major work vectors of the sharded triangular solves (sigp_dist_fit fp32 refinement, sigp_dist_predict) ------------------------------
 // dst [panel][TS_RHS][pw] (float) <- src [rows][lds] (double), zero beyond `cols_valid` and for right-hand sides >= rows
-__global__ void pm_from_rows_kernel(const double* __restrict__ src, long lds, float* __restrict__ dst, int rows, int n_pad, int cols_valid, int pw) {
+template <typename T>
+__global__ void pm_from_rows_kernel(const double* __restrict__ src, long lds, T* __restrict__ dst, int rows, int n_pad, int cols_valid, int pw) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)TS_RHS * n_pad) return;
   const int r = (int)(idx / n_pad), i = (int)(idx % n_pad);
-  dst[((long)(i / pw) * TS_RHS + r) * pw + i % pw] = (r < rows && i < cols_valid) ? (float)src[(long)r * lds + i] : 0.0f;
+  dst[((long)(i / pw) * TS_RHS + r) * pw + i % pw] = (r < rows && i < cols_valid) ? (T)src[(long)r * lds + i] : (T)0;
 }
 // Xacc [rows][ldx] (double) (+)= src panel-major (float)
-__global__ void pm_to_rows_kernel(const float* __restrict__ src, double* __restrict__ Xacc, long ldx, int rows, int n_pad, int pw, int accumulate) {
+template <typename T>
+__global__ void pm_to_rows_kernel(const T* __restrict__ src, double* __restrict__ Xacc, long ldx, int rows, int n_pad, int pw, int accumulate) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long)rows * n_pad) return;
   const int r = (int)(idx / n_pad), i = (int)(idx % n_pad);
   const double v = (double)src[((long)(i / pw) * TS_RHS + r) * pw + i % pw];
   double* o = Xacc + (long)r * ldx + i;
   *o = accumulate ? *o + v : v;
+}
+
+// sigp_dist_predict: cross-covariances of up to TS_RHS test points with every training point, panel-major:
+// dst[(i / pw) TS_RHS + r][i % pw] = k~(xs_r, x_i) for i < n, r < nrhs; 0 otherwise
+template <typename T>
+__global__ void cross_cov_pm_kernel(const double* __restrict__ X, const double* __restrict__ Xs, int dp, int d, int n, int n_pad, int nrhs, T* __restrict__ dst, int pw, KParams kp) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)TS_RHS * n_pad) return;
+  const int r = (int)(idx / n_pad), i = (int)(idx % n_pad);
+  double v = 0.0;
+  if (r < nrhs && i < n) {
+    const double* xs = Xs + (long)r * dp;
+    const double* xi = X + (long)i * dp;
+    double sq = 0.0;
+    for (int p = 0; p < d; ++p) { const double t = xs[p] - xi[p]; sq = fma(t, t, sq); }
+    v = cov_from_sq(kp, sq);
+  }
+  dst[((long)(i / pw) * TS_RHS + r) * pw + i % pw] = (T)v;
+}
+// out[r] = sum over this rank's columns of Z[r][c]^2 (r < nrhs; one block per right-hand side, fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void rowsq_kernel(const T* __restrict__ Z, long ldz, int ncol, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double a = 0.0;
+  for (int c = threadIdx.x; c < ncol; c += 256) { const double z = (double)Z[(long)blockIdx.x * ldz + c]; a += z * z; }
+  a = block_reduce_sum(a, sh);
+  if (threadIdx.x == 0) out[blockIdx.x] = a;
 }
 
 }  // namespace sigp

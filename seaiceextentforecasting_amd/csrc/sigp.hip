@@ -131,9 +131,13 @@ struct sigp_handle {
     hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_first[2] = {nullptr, nullptr}, ev_mark = nullptr;
     std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
     // sharded triangular solves of the fp32 refinement: inverses of the own panels' diagonal blocks, panel-major work vectors
-    float* Uinv = nullptr; float* Vinv = nullptr; size_t cap_inv = 0;        // [own panel][PW][PW] each (upper: L_pp^-T, lower: L_pp^-1)
-    float* invP = nullptr; size_t cap_invP = 0;                              // scratch of one inversion
-    float* ft = nullptr; float* fx = nullptr; float* fr = nullptr; float* fc = nullptr; size_t cap_vec = 0; size_t cap_ft = 0;
+    // (element type = the handle's: fp32 for the refinement of an fp32 fit, the handle's own for sigp_dist_predict)
+    void* Uinv = nullptr; void* Vinv = nullptr; size_t cap_inv = 0;          // [own panel][PW][PW] each (upper: L_pp^-T, lower: L_pp^-1)
+    void* invP = nullptr; size_t cap_invP = 0;                               // scratch of one inversion
+    void* ft = nullptr; void* fx = nullptr; void* fr = nullptr; void* fc = nullptr; size_t cap_vec = 0; size_t cap_ft = 0;
+    // sigp_dist_predict after a sharded fit: alpha~ = K~^-1 y replicated (fp64), results of a prediction call
+    bool fit_ok = false, inv_ready = false, alpha_ready = false;
+    double* alpha = nullptr; double* pred = nullptr; size_t cap_pred = 0;
     long cap_ref_npad = 0;                     // order the fp64 refinement vectors (xq, rq, rpart, fpart) of a sharded fp32 fit are sized for
     double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
     // statistics of the last sharded fit (sigp_get_stat "dist_*")

@@ -277,10 +277,21 @@ class DistributedGPR:
         return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks", "host_comm_ms", "enqueue_ms")}
 
     def predict(self, Xs):
+        """(fmean [m], fvar [m]) as ``GPR.predict``.  The points passed to ``fit(Xs=...)`` rode along the factorisation and cost nothing;
+        any other points go through ``sigp_dist_predict`` (solves on the distributed factor) -- a COLLECTIVE call: every rank must
+        make it with the same ``Xs`` (RBF / Matern)."""
+        from . import _lib as L
         if self._own_ride is None:
             raise RuntimeError("predict: call fit() first")
         ride, mu, var = self._own_ride
-        Xs = np.atleast_2d(np.asarray(Xs, dtype=np.float64))
-        if ride is None or Xs.shape != ride.shape or not np.array_equal(Xs, ride):
-            raise RuntimeError("sharded fit: the factor is spread over the ranks; predictions exist for the points passed to fit(Xs=...)")
-        return mu.copy(), var.copy()
+        Xs = L.f64(np.atleast_2d(np.asarray(Xs, dtype=np.float64)), 2)
+        if ride is not None and Xs.shape == ride.shape and np.array_equal(Xs, ride):
+            return mu.copy(), var.copy()
+        if self.gp.kernel == "netdiffusion":
+            raise RuntimeError("sharded fit with the reference kernel: predictions exist for the points passed to fit(Xs=...)")
+        if Xs.shape[1] != self.gp.d:
+            raise ValueError("Xs must have %d columns" % self.gp.d)
+        m = Xs.shape[0]
+        mean, v = np.zeros(m), np.zeros(m)
+        self.gp._check(self.gp._lib.sigp_dist_predict(self.gp._h, L.ptr(Xs), m, Xs.shape[1], L.ptr(mean), L.ptr(v)), "dist_predict")
+        return mean, v

@@ -98,11 +98,19 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
                 assert dg.matrix_bytes_ <= 0.75 * one[2], (dg.matrix_bytes_, one[2])
             st = dg.stats()
             assert st["fit_ms"] > 0 and (world == 1 or P == 1 or st["bcast_bytes"] > 0), st      # (the last panel has no reader: it does not travel)
-            try:
-                dg.predict(Xs + 1.0)
-                raise SystemExit("expected RuntimeError")
-            except RuntimeError:
-                pass
+            if kind == "netdiffusion":                       # the reference kernel's test points ride along the fit; nothing else
+                try:
+                    dg.predict(Xs + 1.0)
+                    raise SystemExit("expected RuntimeError")
+                except RuntimeError:
+                    pass
+            else:                                            # any other points: sigp_dist_predict (collective), solves on the distributed factor
+                Xn = np.vstack([Xs[:2] + 0.25, np.random.default_rng(n).standard_normal((5, d))])      # 7 points: a pass of 4 and a pass of 3
+                mu2, var2 = dg.predict(Xn)
+                ref2 = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
+                assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la, rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]))
+                mu3, var3 = dg.predict(Xn[3:4])              # again (alpha~ and the inverses are kept), one point
+                assert np.array_equal(mu3, mu2[3:4]) and np.array_equal(var3, var2[3:4])
             dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
             assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
     assert np.array_equal(bits[0][0], bits[1][0]) and np.array_equal(bits[0][1], bits[1][1]) and bits[0][2] == bits[1][2], "look-ahead changed the bits"
@@ -132,6 +140,10 @@ for kind, n, d, W, m in (("matern52", 900, 16, 2, 2), ("rbf", 2049, 32, 3, 3), (
             if m:
                 mu, var = dg.predict(Xs)
                 assert rel(mu, ref["fmean"]) <= 1e-6 and rel(var, ref["fvar"]) <= 1e-5, (kind, n, rank, la, rel(mu, ref["fmean"]), rel(var, ref["fvar"]))
+            Xn = np.random.default_rng(n + 1).standard_normal((6, d))          # new points: mean from the refined alpha~, variance from the fp32 factor
+            mu2, var2 = dg.predict(Xn)
+            ref2 = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
+            assert rel(mu2, ref2["fmean"]) <= 1e-6 and rel(var2, ref2["fvar"]) <= 1e-3, (kind, n, rank, la, rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]))
             T = -(-n // 128); P = -(-T // W)
             mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
             assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 4) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)   # fp32: half the bytes, ~ 1/world
@@ -376,6 +388,9 @@ for kind, dtype, n, d, W, m, sn in cases:
     ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
     fab = Fabric(world)
     out = [None] * world
+    pred = [None] * world
+    Xnew = np.ascontiguousarray(np.random.default_rng(n).standard_normal((5, d)))
+    refn = O.fit_predict(X, y, Xnew, ell, sn, kind=kind, ref_idiom=False)
     def run(rank):
         try:
             rk = Rank(fab, rank)
@@ -390,6 +405,10 @@ for kind, dtype, n, d, W, m, sn in cases:
                 assert rc == 0, (rc, lib.sigp_last_error(gp._h))
                 res.append((o4.copy(), mean.copy(), var.copy()))
             out[rank] = res
+            pm, pv = np.zeros(5), np.zeros(5)                         # new points through the distributed solves (their small collectives too)
+            rc = lib.sigp_dist_predict(gp._h, L.ptr(Xnew), 5, Xnew.shape[1], L.ptr(pm), L.ptr(pv))
+            assert rc == 0, (rc, lib.sigp_last_error(gp._h))
+            pred[rank] = (pm, pv)
             lib.sigp_dist_shutdown(gp._h); gp.close()
         except BaseException as e:
             failures.append((kind, dtype, n, rank, repr(e)))
@@ -404,6 +423,9 @@ for kind, dtype, n, d, W, m, sn in cases:
         for o4, mean, var in out[rank]:
             assert rel(mean, ref["fmean"]) <= tol[0] and rel(var, ref["fvar"]) <= tol[1] and rel(o4[1], ref["nlml"]) <= tol[2], (kind, dtype, n, rank, rel(mean, ref["fmean"]), rel(var, ref["fvar"]))
             assert np.array_equal(mean, out[0][0][1]) and np.array_equal(var, out[0][0][2]) and o4[1] == out[0][0][0][1], (kind, dtype, n, rank, "ranks / repetitions disagree")
+    for rank in range(world):
+        assert rel(pred[rank][0], refn["fmean"]) <= tol[0] and rel(pred[rank][1], refn["fvar"]) <= (1e-8 if dtype == "f64" else 1e-3), (kind, dtype, n, rank, "dist_predict")
+        assert np.array_equal(pred[rank][0], pred[0][0]) and np.array_equal(pred[rank][1], pred[0][1])
     print("ok", kind, dtype, n, flush=True)
 open(os.path.join(%(out)r, "ok_async"), "w").write("ok")
 '''
