@@ -37,6 +37,15 @@ for case in range(cases):
         got = {"nlml": dg.nlml_, "sigma_f": dg.sigma_f_}
         if m:
             got["mean"], got["var"] = dg.predict(Xs)
+        if kind != "netdiffusion" and case % 2 == 0:        # new points through sigp_dist_predict
+            Xn = np.random.default_rng(case).standard_normal((int(rng.integers(1, 10)), d))
+            refn = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
+            mn, vn = dg.predict(Xn)
+            em = float(np.max(np.abs(mn - refn["fmean"])) / max(np.max(np.abs(refn["fmean"])), 1e-300)); ev = float(np.max(np.abs(vn - refn["fvar"]) / np.abs(refn["fvar"])))
+            worst[(dtype, "new_mean")] = max(worst.get((dtype, "new_mean"), 0.0), em); worst[(dtype, "new_var")] = max(worst.get((dtype, "new_var"), 0.0), ev)
+            if not (em <= (1e-8 if dtype == "f64" else 1e-6) and ev <= (1e-8 if dtype == "f64" else 2e-3)):
+                fails += 1
+                print("rank %d FAIL case %d n=%d d=%d %s %s W=%d: dist_predict mean %.2e var %.2e" % (rank, case, n, d, kind, dtype, W, em, ev), flush=True)
         if dtype == "f32":
             assert (0 < dg.refine_residual_ or n <= 4) and dg.refine_residual_ <= 1e-9, (case, n, dg.refine_residual_)   # (orders 1-4 can be solved exactly)
     tol = {"mean": 1e-8, "var": 1e-8, "nlml": 1e-9, "sigma_f": 1e-8} if dtype == "f64" else {"mean": 1e-6, "var": 1e-5, "nlml": 5e-5, "sigma_f": 1e-6}
