@@ -147,6 +147,22 @@ for kind, n, d, W, m in (("matern52", 900, 16, 2, 2), ("rbf", 2049, 32, 3, 3), (
             T = -(-n // 128); P = -(-T // W)
             mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
             assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 4) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)   # fp32: half the bytes, ~ 1/world
+# the full ride block (127 test points) through the sharded fit; sigp_dist_predict refuses to run before a fit
+X, y, Xs = O.synthetic_problem(700, 6, 98, m=127)
+ref = O.fit_predict(X, y, Xs, 2.0, 1e-2, kind="rbf", ref_idiom=False)
+with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=2) as dg:
+    try:
+        dg.predict(Xs)
+        raise SystemExit("expected RuntimeError")
+    except RuntimeError:
+        pass
+    import ctypes as C
+    from seaiceextentforecasting_amd import _lib as L
+    one = np.zeros(1)
+    assert dg.gp._lib.sigp_dist_predict(dg.gp._h, L.ptr(np.zeros((1, 6))), 1, 6, L.ptr(one), L.ptr(one)) == L.BAD_ARG
+    dg.fit(X, y, 2.0, 1e-2, Xs=Xs)
+    mu, var = dg.predict(Xs)
+    assert rel(mu, ref["fmean"]) <= 1e-8 and rel(var, ref["fvar"]) <= 1e-8
 # non-SPD: every rank learns the first failing pivot from the MIN all-reduce and raises like np.linalg.cholesky
 X, y, Xs = O.synthetic_problem(700, 6, 99, m=1)
 X[300:350] = X[100:150]
