@@ -395,6 +395,25 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
   static AttrOnce attr;
   HIPCHK(h, attr.set(h->device, (const void*)syrk128_kernel<T, SET>, SY_LDS_BYTES));
 #ifdef SIGP_DEBUG_TOOLS   // tile-walk experiments (persistent grid, XCD-chunked walk): measured slower, libsigp_debug.so only
+  if (g.dbg & (3 | 512)) {  // timing ablations of the K loop (tools/syrk_bench.py): dbg 1 no in-loop DMA, 2 no in-loop fragment reads, 512 no MFMA
+    auto go = [&](auto abl) -> int {
+      constexpr int A = decltype(abl)::value;
+      static AttrOnce attr_a;
+      HIPCHK(h, attr_a.set(h->device, (const void*)syrk128_kernel<T, SET, false, A>, SY_LDS_BYTES));
+      hipLaunchKernelGGL((syrk128_kernel<T, SET, false, A>), dim3(nt, std::max(1, g.batch), std::max(1, g.zcount)), dim3(256), SY_LDS_BYTES, st, g);
+      HIPCHK(h, hipGetLastError());
+      return SIGP_OK;
+    };
+    switch ((g.dbg & 3) | ((g.dbg & 512) ? 4 : 0)) {
+      case 1: return go(std::integral_constant<int, 1>{});
+      case 2: return go(std::integral_constant<int, 2>{});
+      case 3: return go(std::integral_constant<int, 3>{});
+      case 4: return go(std::integral_constant<int, 4>{});
+      case 5: return go(std::integral_constant<int, 5>{});
+      case 6: return go(std::integral_constant<int, 6>{});
+      default: return go(std::integral_constant<int, 7>{});
+    }
+  }
   const long total = (long)nt * std::max(1, g.batch);
   if (may_persist && h->persist_now && h->opt_update_wgs > 0 && g.patch == 0 && total > h->opt_update_wgs) {
     GemmArgsT<T> gp = g;

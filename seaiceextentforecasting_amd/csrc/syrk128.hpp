@@ -11,6 +11,7 @@
 //   * the sign is folded into the accumulator (acc = -C; acc += A B^T; C = -acc) so A needs no negation.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "gemm_mfma.hpp"
 
@@ -30,7 +31,7 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // One 128x128 tile:  C (-)= A[128 x K] B[128 x K]^T.  Ag / Bg point at the tile's first A / B row, Cw at THIS WAVE's
 // 64x64 quadrant of the C tile.  All 256 threads of the workgroup call it together (it contains barriers); As / Bs are
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
-template <typename T, bool SET>
+template <typename T, bool SET, int ABL = 0>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
                                              long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1,
                                              int tid_in = -1) {
@@ -130,9 +131,11 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   const int arow0 = (wm * 64 + lr) * KTe, brow0 = (wn * 64 + lr) * KTe;
 
   // Software pipeline (2 LDS buffers, one barrier per K-slice, placed MID-slice):
-  //   read group-1 fragments of slice s | MFMA group 0 | barrier (slice s+1 landed, slice s fully read)
-  //   | DMA slice s+2 into the buffer just freed, read group-0 fragments of slice s+1 | MFMA group 1
-  // so every fragment read and every DMA has a whole MFMA group (2048 cycles) to land behind.
+  //   MFMA group 0 with the 8 group-1 fragment reads of slice s spread through it | barrier (slice s+1 landed, slice s fully read)
+  //   | MFMA group 1 with the 8 DMA instructions of slice s+2 (into the buffer just freed) and the 8 group-0 fragment reads of
+  //   slice s+1 spread through it
+  // so every fragment read and every DMA has most of an MFMA group to land behind AND costs the wave no issue time of its own:
+  // as bursts between the groups the loads cost the fp32 kernel 14 % and the fp64 kernel 4-5 % (A/B with the DMA switched off).
   const int nst = K / KTe;
   v16_t a0[4], b0[4], a1[4], b1[4];
   SY_ISSUE(0, 0);
@@ -143,30 +146,36 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bs + brow0 + j * 16 * KTe + fo0);
-  for (int s = 0; s < nst; ++s) {
+  // The loads sit INSIDE the MFMA groups (sched_group_barrier recipes: one load, G/8 MFMAs, ...).  The DMA is unconditional inside the
+  // steady-state loop (a branch would cut the scheduling region); the last two slices run without it.  ABL (debug library only):
+  // bit 0 no in-loop DMA, bit 1 no in-loop fragment reads, bit 2 no MFMA -- timing ablations as template arguments, so that the product kernel
+  // and the debug library's ABL = 0 kernel are the same code.
+  auto slice = [&](int s, auto with_dma) __attribute__((always_inline)) {
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
     const T* Bb = Bs + buf * SY_T * KTe + brow0;
-    if (!(dbg & 2) || s == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
+    for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (dbg & 64) __builtin_amdgcn_s_setprio(1);
+    for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
+    if (!(ABL & 4))
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
-    if (dbg & 64) __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {                       // reads early, one per MFMA (the first MFMA leads: its operands' wait -- lgkmcnt(0) --
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // would otherwise wait for the first of these reads as well), then the rest of the group
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, NE * 16 - 8, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(dbg & 4)) __syncthreads();
+    __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < nst && !(dbg & 1)) SY_ISSUE((s + 2) * KTe, buf);
-    if (s + 1 < nst && !(dbg & 2)) {
+    if (decltype(with_dma)::value && !(ABL & 1)) SY_ISSUE((s + 2) * KTe, buf);
+    if ((decltype(with_dma)::value || s + 1 < nst) && !(ABL & 2)) {
       const T* An = As + (buf ^ 1) * SY_T * KTe + arow0;
       const T* Bn = Bs + (buf ^ 1) * SY_T * KTe + brow0;
 #pragma unroll
@@ -174,14 +183,33 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bn + j * 16 * KTe + fo0);
     }
-    __builtin_amdgcn_sched_barrier(0);
+    if (!(ABL & 4))
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
+    if (decltype(with_dma)::value) {
+      // the DMA first (it is waited for one group + one barrier later: every MFMA it is issued behind comes off its lead), then the reads
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, NE * 16 - 16, 1);
+    }
     __builtin_amdgcn_sched_barrier(0);
+  };
+  {
+    int s = 0;
+    for (; s + 2 < nst; ++s) slice(s, std::true_type{});
+    for (; s < nst; ++s) slice(s, std::false_type{});
   }
 #undef SY_ISSUE
   if (stamp) ph1 = __builtin_amdgcn_s_memtime();   // K loop issued
@@ -204,7 +232,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   }
 }
 
-template <typename T, bool SET, bool PERSIST = false>
+template <typename T, bool SET, bool PERSIST = false, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   constexpr int KTe = Num<T>::KT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -242,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     int tid_t = tid;
     if (PERSIST) asm volatile("" : "+v"(tid_t));   // opaque per tile: keeps the lane-dependent address arithmetic of the tile inside the
                                                    // loop (hoisted, it costs 18 VGPRs that do not exist: the kernel would spill to scratch)
-    syrk128_tile<T, SET>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+    syrk128_tile<T, SET, ABL>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
     if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
       __builtin_amdgcn_s_waitcnt(0);
       if (tid == 0) {

@@ -18,14 +18,15 @@ if mode == "ablate":
     print("rt   K small dbg |    ms   TFLOP/s")
     for rt, K in ((62, 1024), (62, 2048)):
         for small in (2,):
-            for dbg in (0, 64, 0, 64):
+            for dbg in (0, 1, 0, 1):
                 lib.sigp_debug_time_syrk(h, rt, K, 0, small, 5, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
                 print("%2d %4d %5d %3d | %6.3f  %6.1f   in-kernel clock %.2f GHz" % (rt, K, small, dbg, ms.value, tf.value, ghz.value))
 elif mode == "ablate2":
-    # dbg bits: 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no C load, 16 no C store  (timing only; results are garbage)
+    # dbg bits: 1 no in-loop DMA, 2 no in-loop fragment reads, 512 no MFMA (compile-time variants of the kernel), 8 no C load,
+    # 16 no C store  (timing only; results are garbage)
     print("rt   K dbg |    ms   TFLOP/s  clock")
     for rt, K in ((90, 1024), (90, 4096)):
-        for dbg in (0, 1, 4, 5, 2, 3, 7, 24, 25, 31, 0):
+        for dbg in (0, 1, 2, 3, 24, 25, 27, 0):
             lib.sigp_debug_time_syrk(h, rt, K, 0, 2, 4, C.byref(ms), C.byref(tf), dbg, C.byref(ghz))
             print("%2d %4d %3d | %6.3f  %6.1f   %.2f GHz" % (rt, K, dbg, ms.value, tf.value, ghz.value), flush=True)
 elif mode == "f32":
