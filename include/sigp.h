@@ -262,6 +262,8 @@ int sigp_profile_reset(sigp_handle* h);
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count
  *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
+ *   refine_stored [1]     fp32 engine: the covariance build also writes K~ in fp64 (8 n^2 bytes per lockstep member, skipped above 40 GB) and the
+ *                         refinement's residuals read it (HBM-bound) instead of recomputing n^2 covariances each; 0 = recompute (no extra memory)
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
  *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:

@@ -65,7 +65,8 @@ struct alignas(4 * sizeof(TO)) KbOut4 { TO v[4]; };
 template <typename TO, int DC = KB_DC>
 __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
                                                      TO* __restrict__ Mat, long strideM, long ld,
-                                                     const KParams* __restrict__ kps, int flags_in, int colblk0 = 0) {
+                                                     const KParams* __restrict__ kps, int flags_in, int colblk0 = 0,
+                                                     double* __restrict__ Mat64 = nullptr, long stride64 = 0) {
   const int flags = flags_in & (DBG_MASK | 1 | 8 | 16);
   const int full = flags & 1;      // flag bits 2 / 4: timing ablations (no covariance function / no store)
   int bi, bj;                      // 64-row tile, 128-column tile
@@ -133,12 +134,17 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
   for (int s = 0; s < 8; ++s) {
     const int gi = bi * KB_TM + rg + 8 * s, gj = bj * KB_TN + c4;
     KbOut4<TO> o;
+    KbOut4<double> o64;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      if (gi >= n) o.v[c] = (TO)((gi == gj + c && !full) ? 1.0 : 0.0);
-      else o.v[c] = (TO)((gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq(kp, acc[s][c])) + (gi == gj + c ? kp.sn : 0.0) : 0.0);
+      double v;
+      if (gi >= n) v = (gi == gj + c && !full) ? 1.0 : 0.0;
+      else v = (gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq(kp, acc[s][c])) + (gi == gj + c ? kp.sn : 0.0) : 0.0;
+      o.v[c] = (TO)v; o64.v[c] = v;
     }
     if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + (mcol >= 0 ? mcol + c4 : (long)gj)) = o;
+    // the same tile in fp64 beside a lower-precision one (fp32 engine: what the refinement's residuals read), same [row][ld] layout
+    if (Mat64 != nullptr) *(KbOut4<double>*)(Mat64 + blockIdx.z * stride64 + (long)gi * ld + gj) = o64;
   }
 }
 
@@ -668,6 +674,93 @@ __global__ __launch_bounds__(256) void krefine_residual_kernel(const double* __r
   if (i >= iend) return;
 #pragma unroll
   for (int r = 0; r < 4; ++r) part[((long)blockIdx.y * 4 + r) * ldp + i] = acc[r];
+}
+// The same partial sums from a STORED fp64 K~ -- the lower triangle the covariance build wrote beside the fp32 matrix (kbuild_kernel's
+// Mat64; the diagonal 128-blocks are complete) -- in two passes over it, both coalesced:
+//   columns: thread i walks column i downwards, sum_{j >= i} K~[j][i] x[j] (= the upper part of row i by symmetry, and the diagonal);
+//            a wavefront reads 64 consecutive doubles of row j.  Rows in gridDim.y chunks of jlen, partial (chunk, r, i) as above.
+//   rows:    one wavefront per row i, lanes along it, sum_{j < i} K~[i][j] x[j]; one more partial, index `chunk_out`.
+// One 8-byte load + nrhs FMAs per element: HBM-bound (8 n^2 bytes per residual) where the on-the-fly kernel is bound by its d
+// subtract-multiplies + one exp per element (5.3 ms at n = 32768, d = 32).
+__global__ __launch_bounds__(256) void kres_lower_cols_kernel(const double* __restrict__ Kq, long ldk, int n, int nrhs,
+                                                              const double* __restrict__ Xq, long ldq, double* __restrict__ part,
+                                                              long ldp, int jlen) {
+  __shared__ double Q[4][256];
+  const int ib = blockIdx.x * 256, i = ib + threadIdx.x;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int jbeg = blockIdx.y * jlen, jend = min(n, jbeg + jlen);
+  if (jend > ib) {
+    const double* col = Kq + (i < n ? i : 0);
+    for (int j0 = max(jbeg, ib & ~255); j0 < jend; j0 += 256) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Q[r][threadIdx.x] = (r < nrhs && j0 + (int)threadIdx.x < jend) ? Xq[(long)r * ldq + j0 + threadIdx.x] : 0.0;
+      __syncthreads();
+      const int jn = min(256, jend - j0);
+      if (j0 >= ib + 256) {            // wholly below this block's diagonal: every row counts for every thread
+        int jj = 0;
+        for (; jj + 8 <= jn; jj += 8) {
+          double kv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) kv[u] = col[(long)(j0 + jj + u) * ldk];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fma(kv[u], Q[r][jj + u], acc[r]);
+        }
+        for (; jj < jn; ++jj) {
+          const double kv = col[(long)(j0 + jj) * ldk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = fma(kv, Q[r][jj], acc[r]);
+        }
+      } else {
+        for (int jj = 0; jj < jn; ++jj) {
+          if (j0 + jj < i || i >= n) continue;
+          const double kv = col[(long)(j0 + jj) * ldk];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = fma(kv, Q[r][jj], acc[r]);
+        }
+      }
+    }
+  }
+  if (i >= n) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) part[((long)blockIdx.y * 4 + r) * ldp + i] = acc[r];
+}
+__global__ __launch_bounds__(256) void kres_lower_rows_kernel(const double* __restrict__ Kq, long ldk, int n, int nrhs,
+                                                              const double* __restrict__ Xq, long ldq, double* __restrict__ part,
+                                                              long ldp, int chunk_out) {
+  __shared__ double Q[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;                 // this wavefront's row
+  const int iend = min(n, (int)blockIdx.x * 4 + 4);    // the workgroup's rows are [4 blockIdx.x, iend): columns below iend - 1 matter to someone
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const double* row = Kq + (long)(i < n ? i : 0) * ldk;
+  for (int j0 = 0; j0 < iend - 1; j0 += 256) {
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Q[r][threadIdx.x] = (r < nrhs && j0 + (int)threadIdx.x < n) ? Xq[(long)r * ldq + j0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (i < n) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + lane + 64 * u;
+        if (j < i) {
+          const double kv = row[j];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = fma(kv, Q[r][lane + 64 * u], acc[r]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[r] += __shfl_xor(acc[r], off, 64);
+  if (i < n && lane == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[((long)chunk_out * 4 + r) * ldp + i] = acc[r];
+  }
 }
 template <int DREG>
 __global__ __launch_bounds__(256) void krefine_finish_kernel(const double* __restrict__ X, const double* __restrict__ Xs,

@@ -87,8 +87,12 @@ struct sigp_handle {
   double* xq = nullptr;      // [4][n_pad] refined solutions: row 0 alpha~ = K~^-1 y, rows 1..m  w_j = K~^-1 k~*_j
   double* rq = nullptr;      // [4][n_pad] fp64 residuals
   double* rpart = nullptr;   // [REFINE_CHUNKS][4][n_pad] partial sums of a residual (krefine_residual_kernel)
+  double* kq = nullptr;      // [G][n_pad][n_pad] fp64 K~ (lower triangle) of the current fp32 fit(s): written by the covariance build beside the fp32 matrix,
+  size_t cap_kq = 0;         // read by the refinement's residuals (kres_lower_*_kernel); nullptr / kq_members = 0: residuals recompute the covariance on the fly
+  int kq_members = 0;
   double* fpart = nullptr;   // partial sums of the final dots
   int opt_refine_iters = 3;
+  int opt_refine_stored = 1; // fp32 fits: the covariance build also writes K~ in fp64 (8 n^2 bytes per member, up to 40 GB) and the refinement's residuals read it instead of recomputing it
   int opt_refine_tol_e = 12; // stop refining once every residual is below 10^-this (relative); 0 = always refine_iters steps
   double refine_resid = 0;   // ||y - K~ alpha~||_inf / ||y||_inf after the last refinement step
   std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
@@ -1143,6 +1147,7 @@ int sigp_destroy(sigp_handle* h) {
   if (h->sm_probs) (void)hipFree(h->sm_probs);
   if (h->pred_kps) (void)hipFree(h->pred_kps);
   if (h->gKps) (void)hipFree(h->gKps);
+  if (h->kq) (void)hipFree(h->kq);
   if (h->fmat) (void)hipFree(h->fmat);
   if (h->fdinv) (void)hipFree(h->fdinv);
   if (h->fZ) (void)hipFree(h->fZ);
@@ -1205,6 +1210,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "n64_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_n64_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "wide_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_wide_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "refine_stored")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_stored = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
