@@ -167,6 +167,7 @@ struct sigp_handle {
   int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
                              // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
   int opt_strip_min = 512;
+  int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
@@ -481,6 +482,7 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
     }
 #endif
     if (h->opt_c_dma) g.dbg |= 128;
+    if (DBG_MASK && h->opt_update_dbg) g.dbg |= h->opt_update_dbg & (8 | 16);
     return launch_syrk128_t<T, false>(h, st, g, true);   // tile-walk options (xcd_chunks, update_wgs when persist_now) apply here
   }
   if (nt >= h->opt_small_tiles) {
@@ -1163,7 +1165,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!h || !name) return SIGP_BAD_ARG;
   {   // measurement switches and rejected experiments: their code is compiled into libsigp_debug.so only
     static const char* const dbg_only[] = {"xcd_chunks", "update_wgs", "update_late", "pipeline_head", "head_gate", "wide_tiles", "n64_tiles", "patch",
-                                           "small_nt64", "reserve_cus", "panel_ll", "c_dma", "syrk_v2"};
+                                           "small_nt64", "reserve_cus", "panel_ll", "c_dma", "syrk_v2", "update_dbg"};
     if (!DBG_MASK)
       for (const char* nm : dbg_only)
         if (!strcmp(name, nm)) return fail(h, SIGP_BAD_ARG, "%s is a measurement switch of libsigp_debug.so (make debug), not of the product library", nm);
@@ -1189,6 +1191,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "update_dbg")) { h->opt_update_dbg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "c_dma")) {
     if (!DBG_MASK) return fail(h, SIGP_BAD_ARG, "c_dma is a measurement switch of libsigp_debug.so");
     h->opt_c_dma = value != 0; return SIGP_OK;
