@@ -451,3 +451,15 @@ def test_plain_c_program_runs_the_hot_path_and_the_sharded_fit(tmp_path):
         assert rel(v[3], ref["sigma_f"] * sn) <= tol
         assert rel(v[4:4 + m], ref["fmean"][:m]) <= tol and rel(v[4 + m:4 + 2 * m], ref["fvar"][:m]) <= tol
         assert rel(v[4 + 2 * m:4 + 3 * m], ref["fmean"][m:]) <= tol and rel(v[4 + 3 * m:], ref["fvar"][m:]) <= tol
+
+
+def test_committed_pmc_summary_belongs_to_the_committed_kernel_code():
+    """bench.py quotes roofline.traffic from profiles/r03_pmc_syrk128.json only while the sha of the kernel sources recorded in it equals the
+    tree's (a stale file is refused, and the line then carries traffic = null).  The file committed with the tree must be the tree's."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    pm = json.load(open(os.path.join(root, "profiles", "r03_pmc_syrk128.json")))
+    assert pm["kernel_code_sha16"] == bench.kernel_code_sha16()
+    assert pm["traffic_bytes_per_launch"] > 0 and 0.5 < pm["mfma_pipe_busy_fraction"] <= 1.0
