@@ -317,16 +317,33 @@ __global__ __launch_bounds__(DIAG_THREADS) void potrf_diag_kernel(T* __restrict_
 // nothing: workgroups 0..nb-1 factor (one per lockstep member), every other workgroup is two 256-thread 64x64-tile engines of
 // the generic update (same arithmetic, same k order: bit-identical to separate launches) running in lockstep on equal K.
 static_assert(2 * gemm_lds_bytes<double, 64, 64, false>() <= DIAG_LDS_BYTES, "fp64: the update engines live in the diagonal block's LDS allocation");
+// With the fused chain link (chain_link.hpp) in front of it, the launch has two more jobs: the block row c+1 of column c, L[c+1, c],
+// was left in a scratch block by the link (the link's other workgroups were still reading the unsolved rows) -- `Balt` != nullptr:
+// the riding tiles of block column c+1 (bj < 2 in 64-tile units) read their B operand from it, and nb more workgroups copy it to
+// its place in the matrix (`copy_dst`, row stride lda; nothing in this launch reads it there).
 template <typename T>
 __global__ __launch_bounds__(DIAG_THREADS, 4) void diag_update_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv, int* __restrict__ info,
                                                                    int pivot_base, int flags, long strideA, long strideL, int nb,
-                                                                   GemmArgsT<T> g, int ntile, int wgs) {
+                                                                   GemmArgsT<T> g, int ntile, int wgs, const T* __restrict__ Balt, long sBalt,
+                                                                   T* __restrict__ copy_dst) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if ((int)blockIdx.x < nb) {
     potrf_diag_body<T>(A + blockIdx.x * strideA, lda, Linv + blockIdx.x * strideL, info + blockIdx.x, pivot_base, flags, smem_raw);
     return;
   }
   const int u = (int)blockIdx.x - nb;
+  if (u >= nb * wgs) {                 // copy workgroups: scratch block of member z -> block (c+1, c) of its matrix
+    typedef typename Num<T>::v16_t v16_t;
+    constexpr int CPR = DB * (int)sizeof(T) / 16;          // 16-byte chunks per row
+    const int z = u - nb * wgs;
+    const T* src = Balt + (long)z * sBalt;
+    T* dst = copy_dst + (long)z * strideA;
+    for (int i = (int)threadIdx.x; i < DB * CPR; i += DIAG_THREADS) {
+      const int row = i / CPR, ch = i % CPR;
+      *(v16_t*)(dst + (long)row * lda + ch * (16 / (int)sizeof(T))) = *(const v16_t*)(src + (long)row * DB + ch * (16 / (int)sizeof(T)));
+    }
+    return;
+  }
   const int bz = u / wgs, w = u - bz * wgs;
   const int e = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
   int t = 2 * w + e;
@@ -334,7 +351,11 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void diag_update_kernel(T* __restr
   if (!own) t = ntile - 1;          // odd tile count: the last workgroup's second engine shadows the first (no store)
   int bi = 0, bj = 0;
   gemm_tile_coords(g, t, bi, bj);
-  gemm_tile_body<T, 64, 64, 2, 2, GEMM_SUB, false, 2>(g, bi, bj, (long)bz, (int)threadIdx.x & 255, smem_raw + e * gemm_lds_bytes<T, 64, 64, false>(), own);
+  GemmArgsT<T> gl = g;
+  if (Balt != nullptr && bj < 2) {  // block column c+1: its rows of column c are still in the link's scratch block
+    gl.B = Balt; gl.ldb = DB; gl.sB = sBalt;
+  }
+  gemm_tile_body<T, 64, 64, 2, 2, GEMM_SUB, false, 2>(gl, bi, bj, (long)bz, (int)threadIdx.x & 255, smem_raw + e * gemm_lds_bytes<T, 64, 64, false>(), own);
 }
 
 }  // namespace sigp

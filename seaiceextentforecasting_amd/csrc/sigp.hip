@@ -21,6 +21,7 @@
 #include "gemm_mfma.hpp"
 #include "kernels_misc.hpp"
 #include "potrf_diag.hpp"
+#include "chain_link.hpp"
 #include "smallgp.hpp"
 #include "syrk128.hpp"
 
@@ -48,6 +49,7 @@ struct Slot {
   int* info_host = nullptr;   // pinned
   KParams* kps = nullptr;     // device [capB] per-member hyper-parameters / data-set index
   KParams* kps_host = nullptr;// pinned
+  double* lk = nullptr;       // [capB][128][128] scratch blocks of the fused chain link (chain_link.hpp): L[c+1, c] between the link and the next diagonal block
   double* mt = nullptr; int cap_mt = 0;   // panel_mode 1: [cap_mt][MT_LD][MT_LD] pre-multiplied top blocks (see panel_strip_kernel)
   hipStream_t s_upd = nullptr, s_pan = nullptr;
   hipEvent_t ev_pan = nullptr, ev_la = nullptr, ev_done = nullptr;
@@ -141,7 +143,7 @@ struct sigp_handle {
     void* ft = nullptr; void* fx = nullptr; void* fr = nullptr; void* fc = nullptr; size_t cap_vec = 0; size_t cap_ft = 0;
     // sigp_dist_predict after a sharded fit: alpha~ = K~^-1 y replicated (fp64), results of a prediction call
     bool fit_ok = false, inv_ready = false, alpha_ready = false;
-    double* alpha = nullptr; double* pred = nullptr; size_t cap_pred = 0;
+    double* alpha = nullptr; size_t cap_alpha = 0; double* pred = nullptr; size_t cap_pred = 0;
     long cap_ref_npad = 0;                     // order the fp64 refinement vectors (xq, rq, rpart, fpart) of a sharded fp32 fit are sized for
     double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
@@ -179,9 +181,11 @@ struct sigp_handle {
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
   int opt_first_on_panel = 1;        // right-looking + look-ahead: the update of the next panel's columns runs on the panel stream: 0 never,
                                      // 1 when that panel is a latency chain (not strip-solved: single fits, small groups), 2 always
-  int opt_panel_chain = 3;           // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
+  int opt_panel_chain = 7;           // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
                                      // own, the other columns' update rides in the diagonal-block launch): bit 0 panels that are not strip-solved (single
-                                     // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion
+                                     // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion;
+                                     // bit 2: the chain's two small launches between two diagonal blocks (column solve, next column's update) are
+                                     // ONE launch that does only what the next diagonal block needs (chain_link_kernel), the rest rides
   int opt_chain_rows = 80;           // (see panel_any)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_head_gate = 16;    // pipeline_head = 3: a group's tail begins when at most this many block columns remain behind the panel just enqueued
@@ -279,7 +283,8 @@ void slot_free_buffers(Slot& s) {
   if (s.kps) (void)hipFree(s.kps);
   if (s.kps_host) (void)hipHostFree(s.kps_host);
   if (s.mt) (void)hipFree(s.mt);
-  s.mt = nullptr; s.cap_mt = 0;
+  if (s.lk) (void)hipFree(s.lk);
+  s.mt = nullptr; s.cap_mt = 0; s.lk = nullptr;
   s.mat = s.dinv = s.res = s.res_host = nullptr; s.info = s.info_host = nullptr; s.kps = s.kps_host = nullptr;
   s.capB = 0; s.cap_npad = 0;
 }
@@ -304,6 +309,7 @@ int slot_reserve(sigp_handle* h, Slot& s, long n_pad, int B) {
   HIPCHK(h, hipHostMalloc((void**)&s.info_host, (size_t)nb * sizeof(int)));
   HIPCHK(h, hipMalloc((void**)&s.kps, (size_t)nb * sizeof(KParams)));
   HIPCHK(h, hipHostMalloc((void**)&s.kps_host, (size_t)nb * sizeof(KParams)));
+  HIPCHK(h, hipMalloc((void**)&s.lk, (size_t)nb * NB * NB * sizeof(double)));
   HIPCHK(h, hipDeviceSynchronize());
   s.cap_npad = np; s.capB = nb;
   return SIGP_OK;
@@ -534,6 +540,122 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
   return SIGP_OK;
 }
 
+// ---- a panel as a latency chain ---------------------------------------------------------------------------------------------
+// Block columns [J0, J0 + Wp) of nb lockstep members (already up to date), right-looking and column by column, arranged around the
+// chain  diagonal block c -> what diagonal block c+1 needs -> diagonal block c+1:
+//   fused link (panel_chain bit 2, chain_link.hpp): ONE launch between two diagonal blocks -- its first 36 workgroups form
+//     L[c+1, c] and apply it to block (c+1, c+1); the column solve of the rows below rides in the same launch, the update of every
+//     other block (column c+1 below its diagonal block, the panel's columns c+2..) rides in the launch of diagonal block c+1;
+//   otherwise (and for columns with so many rows below that their solve is chip-filling work for the LDS-DMA kernel): column solve
+//     (all rows), update of column c+1 (all rows), diagonal block c+1 with the update of the columns c+2.. riding.
+// Same k order per tile as the binary recursion either way: bit-identical factors.
+// Mm = (virtual) origin of the storage the panel's columns live in, row stride ld, member stride matStride: a slot's square
+// matrices, or one rank's block columns of a sharded factor (origin shifted so that GLOBAL block indices land in it).
+// rlim = one past the last row block touched (R for a whole panel, J0 + Wp for the top block of a strip-solved panel).
+// on_col (may be null): called once block column c is final in the matrix (the sharded fit streams it to the other ranks).
+template <typename Real>
+int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long matStride, Real* dinvp, long dinvStride, int nb, int J0, int Wp, int rlim,
+                const std::function<int(int)>* on_col = nullptr) {
+  constexpr int diag_lds = diag_lds_bytes<Real>();
+  constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());   // (fp32: the two update engines need more than the block)
+  static AttrOnce du_attr, d_attr, l_attr;
+  HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
+  HIPCHK(h, d_attr.set(h->device, (const void*)potrf_diag_kernel<Real>, diag_lds));
+  HIPCHK(h, l_attr.set(h->device, (const void*)chain_link_kernel<Real>, link_lds_bytes<Real>()));
+  const int flags = h->opt_diag_prio ? 0 : 32;
+  Real* lk = (Real*)s.lk;
+  auto upd_args = [&](int kc, int ccol0, int c0, int c1) {   // columns ccol0 + [c0, c1) -= (column kc)(column kc)^T, rows from each column's diagonal block to rlim
+    const long o = (long)ccol0 * NB;
+    GemmArgsT<Real> g{};
+    g.A = Mm + o * ld + (long)kc * NB; g.lda = ld;
+    g.B = g.A; g.ldb = ld;
+    g.C = Mm + o * ld + o; g.ldc = ld;
+    g.batch = nb; g.sA = g.sB = g.sC = matStride;
+    g.K = NB; g.r0 = 0; g.r1 = rlim - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = 0;
+    return g;
+  };
+  // diagonal block of column c (factor + inverse); gu (64-tile units) = an update whose tiles ride in the launch; linked: the launch follows
+  // a fused link of column c - 1 (B operand of block column c from the scratch block, which is also copied into the matrix)
+  auto diag = [&](int c, const GemmArgsT<Real>* gu, bool linked) -> int {
+    const int ntile = gu ? gemm_grid_size(gu->r0, gu->r1, gu->c0, gu->c1, gu->lower, 0) : 0;
+    const double uflops = gu ? nb * (double)ntile * 2.0 * 64 * 64 * gu->K : 0.0;
+    ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3 + uflops, nb * 3.0 * NB * NB * 8 + nb * (double)ntile * 2.0 * 64 * 64 * sizeof(Real));
+    Real* Ac = Mm + (long)c * NB * ld + (long)c * NB;
+    if (ntile > 0 || linked) {
+      const int wgs = (ntile + 1) / 2;
+      GemmArgsT<Real> g0{};
+      hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(nb + nb * wgs + (linked ? nb : 0)), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info,
+                         c * NB, flags, matStride, dinvStride, nb, gu ? *gu : g0, ntile, wgs, linked ? (const Real*)lk : (const Real*)nullptr, (long)NB * NB,
+                         linked ? Ac - NB : (Real*)nullptr);
+    } else {
+      hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, flags, matStride,
+                         dinvStride);
+    }
+    HIPCHK(h, hipGetLastError());
+    return SIGP_OK;
+  };
+  // rows below the diagonal block of column c:  L[c+1.., c] = A[c+1.., c] inv(L_cc)^T
+  auto solve_column = [&](int c) -> int {
+    const long o = (long)(c + 1) * NB;
+    const int rows_below = rlim - (c + 1);
+    if (rows_below <= 0) return SIGP_OK;
+    GemmArgsT<Real> g{};
+    g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
+    g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
+    g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
+    g.batch = nb; g.sA = g.sC = matStride; g.sB = dinvStride;
+    g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
+    ProfScope ps(h, sp, SIGP_KC_TRSM, nb * 2.0 * rows_below * NB * NB * NB, nb * 2.0 * rows_below * NB * NB * 8);
+    if (rows_below * nb >= h->opt_trsm128) {   // enough 128-row tiles to fill the chip: the LDS-DMA kernel
+      g.r1 = rows_below;
+      return launch_syrk128_t<Real, true>(h, sp, g);
+    }
+    g.r1 = rows_below * 4;                     // few rows: 32-row tiles for parallelism
+    return launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g);
+  };
+  int rc = diag(J0, nullptr, false);
+  if (rc) return rc;
+  for (int i = 0; i < Wp; ++i) {
+    const int c = J0 + i;
+    const int rows_below = rlim - (c + 1);
+    const bool last = i + 1 >= Wp;
+    const bool fused = !last && (h->opt_panel_chain & 4) != 0 && rows_below >= 1 && (long)rows_below * nb < h->opt_trsm128;
+    if (!fused) {
+      if ((rc = solve_column(c))) return rc;
+      if (on_col && (rc = (*on_col)(c))) return rc;
+      if (last) break;
+      if ((rc = gemm_sub_auto(h, sp, upd_args(c, c + 1, 0, 1)))) return rc;
+      const int rest = Wp - i - 2;                             // columns c+2 .. J0+Wp-1
+      if (rest > 0) {
+        GemmArgsT<Real> gu = upd_args(c, c + 1, 1, 1 + rest);
+        gu.r0 *= 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2;
+        rc = diag(c + 1, &gu, false);
+      } else {
+        rc = diag(c + 1, nullptr, false);
+      }
+      if (rc) return rc;
+      continue;
+    }
+    {
+      LinkArgsT<Real> a{};
+      a.Acol = Mm + (long)(c + 1) * NB * ld + (long)c * NB; a.ld = ld;
+      a.Linv = dinvp + (long)c * NB * NB;
+      a.Cdiag = Mm + (long)(c + 1) * NB * ld + (long)(c + 1) * NB;
+      a.scratch = lk;
+      a.sM = matStride; a.sL = dinvStride; a.sS = (long)NB * NB;
+      a.rows_ride = rows_below - 1;
+      ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (2.0 * rows_below * NB * NB * NB + (double)NB * NB * NB), nb * 2.0 * rows_below * NB * NB * 8);
+      hipLaunchKernelGGL(chain_link_kernel<Real>, dim3((unsigned)(LINK_CHAIN_WGS + 4 * a.rows_ride), (unsigned)nb), dim3(256), link_lds_bytes<Real>(), sp, a);
+      HIPCHK(h, hipGetLastError());
+    }
+    GemmArgsT<Real> gu = upd_args(c, c + 1, 0, Wp - i - 1);    // columns c+1 .. J0+Wp-1 from row block c+2 down (block (c+1, c+1) is done)
+    gu.r0 = 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2;
+    if ((rc = diag(c + 1, &gu, true))) return rc;
+    if (on_col && (rc = (*on_col)(c))) return rc;              // (block row c+1 of column c reached the matrix in that launch)
+  }
+  return SIGP_OK;
+}
+
 // ---- blocked Cholesky of the nb lockstep members of slot s (each augmented with its ride rows) --------
 // Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
 // GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
@@ -591,7 +713,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
       const int wgs = (ntile + 1) / 2;
       hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(nb + nb * wgs), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info,
-                         c * NB, flags, matStride, dinvStride, nb, *gu, ntile, wgs);
+                         c * NB, flags, matStride, dinvStride, nb, *gu, ntile, wgs, (const Real*)nullptr, 0L, (Real*)nullptr);
     } else {
       hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB,
                          flags, matStride, dinvStride);
@@ -642,29 +764,9 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, J0, hw, J0 + hw, 0, Wp - hw, rlim))) return rc;
     return panel_rec(J0 + hw, Wp - hw, rlim);
   };
-  // The same panel, right-looking and column by column (same k order per tile: bit-identical), arranged around the latency chain
-  // diagonal block -> column solve -> update of the NEXT column -> next diagonal block: the update of the panel's other columns
-  // (most of the in-panel flops) rides in the launch of the next diagonal block (diag_update_kernel), so the chain never waits
-  // for it and no second stream is involved.
+  // The same panel as a latency chain (chain_panel above): right-looking column by column, bit-identical to the recursion.
   auto panel_chain = [&](int J0, int Wp, int rlim) -> int {
-    int rc = diag_block(J0, nullptr);
-    if (rc) return rc;
-    for (int i = 0; i < Wp; ++i) {
-      const int c = J0 + i;
-      if ((rc = solve_column(c, rlim))) return rc;
-      if (i + 1 >= Wp) break;
-      if ((rc = update(sp, SIGP_KC_UPDATE_SMALL, c, 1, c + 1, 0, 1, rlim))) return rc;
-      const int rest = Wp - i - 2;                             // columns c+2 .. J0+Wp-1
-      if (rest > 0) {
-        GemmArgsT<Real> gu = update_args(c, 1, c + 1, 1, 1 + rest, rlim);
-        gu.r0 *= 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2; gu.patch = 0;
-        rc = diag_block(c + 1, &gu);
-      } else {
-        rc = diag_block(c + 1, nullptr);
-      }
-      if (rc) return rc;
-    }
-    return SIGP_OK;
+    return chain_panel<Real>(h, s, sp, M, ld, matStride, dinvp, dinvStride, nb, J0, Wp, rlim);
   };
   // top = the top block of a strip-solved panel.  A whole panel takes the chain form only while its riding updates (K = 128, 64x64
   // tiles: 4 flop per operand byte) stay shorter than the diagonal block they ride beside: up to chain_rows (80) 128-row blocks x
@@ -863,67 +965,7 @@ template <typename Real>
 int dist_panel(sigp_handle* h, Slot& s, Real* Mm, long ld, Real* dinvp, hipStream_t sp, long n_pad, int J0, int Wp, const std::function<int(int)>* on_col = nullptr) {
   const int T = (int)(n_pad / NB), R = T + 1;
   if (!(h->opt_panel_chain & 1) || Wp <= 2 || (long)(R - J0) > h->opt_chain_rows) return dist_panel_rec<Real>(h, s, Mm, ld, dinvp, sp, n_pad, J0, Wp, on_col);
-  constexpr int diag_lds = diag_lds_bytes<Real>();
-  constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());
-  static AttrOnce du_attr, d_attr;
-  HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
-  HIPCHK(h, d_attr.set(h->device, (const void*)potrf_diag_kernel<Real>, diag_lds));
-  auto upd_args = [&](int kc, int ccol0, int c0, int c1) {
-    const long o = (long)ccol0 * NB;
-    GemmArgsT<Real> g{};
-    g.A = Mm + o * ld + (long)kc * NB; g.lda = ld;
-    g.B = g.A; g.ldb = ld;
-    g.C = Mm + o * ld + o; g.ldc = ld;
-    g.batch = 1; g.K = NB; g.r0 = 0; g.r1 = R - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1;
-    return g;
-  };
-  auto diag = [&](int c, const GemmArgsT<Real>* gu) -> int {
-    Real* Ac = Mm + (long)c * NB * ld + (long)c * NB;
-    const int ntile = gu ? gemm_grid_size(gu->r0, gu->r1, gu->c0, gu->c1, 1, 0) : 0;
-    if (ntile > 0) {
-      const int wgs = (ntile + 1) / 2;
-      hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(1 + wgs), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L, 1,
-                         *gu, ntile, wgs);
-    } else {
-      hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(1), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, 0, 0L, 0L);
-    }
-    HIPCHK(h, hipGetLastError());
-    return SIGP_OK;
-  };
-  int rc = diag(J0, nullptr);
-  if (rc) return rc;
-  for (int i = 0; i < Wp; ++i) {
-    const int c = J0 + i;
-    const long o = (long)(c + 1) * NB;
-    const int rows_below = R - (c + 1);
-    if (rows_below > 0) {
-      GemmArgsT<Real> g{};
-      g.A = Mm + o * ld + (long)c * NB; g.lda = ld;
-      g.B = dinvp + (long)c * NB * NB; g.ldb = NB;
-      g.C = Mm + o * ld + (long)c * NB; g.ldc = ld;
-      g.batch = 1; g.K = NB; g.r0 = 0; g.c0 = 0; g.c1 = 1; g.lower = 0;
-      if (rows_below >= h->opt_trsm128) {          // enough 128-row tiles to fill the chip: the LDS-DMA kernel (as potrf_core's solve_column)
-        g.r1 = rows_below;
-        if ((rc = launch_syrk128_t<Real, true>(h, sp, g))) return rc;
-      } else {
-        g.r1 = rows_below * 4;
-        if ((rc = launch_gemm_cfg<Real, 32, 128, 1, 4, GEMM_SET, false>(h, sp, g))) return rc;
-      }
-    }
-    if (on_col && (rc = (*on_col)(c))) return rc;
-    if (i + 1 >= Wp) break;
-    if ((rc = gemm_sub_auto(h, sp, upd_args(c, c + 1, 0, 1)))) return rc;
-    const int rest = Wp - i - 2;
-    if (rest > 0) {
-      GemmArgsT<Real> gu = upd_args(c, c + 1, 1, 1 + rest);
-      gu.r0 *= 2; gu.r1 *= 2; gu.c0 *= 2; gu.c1 *= 2;
-      rc = diag(c + 1, &gu);
-    } else {
-      rc = diag(c + 1, nullptr);
-    }
-    if (rc) return rc;
-  }
-  return SIGP_OK;
+  return chain_panel<Real>(h, s, sp, Mm, ld, 0L, dinvp, 0L, 1, J0, Wp, R, on_col);
 }
 
 template <typename Real>
@@ -1215,7 +1257,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_stored")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_stored = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 7) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
   if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "head_gate")) { if (value < 0) return SIGP_BAD_ARG; h->opt_head_gate = (int)value; return SIGP_OK; }

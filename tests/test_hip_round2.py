@@ -388,7 +388,7 @@ def test_panel_chain_and_first_update_placement_are_schedules_only(S, dtype):
     for n, W in ((2300, 8), (1100, 4), (700, 16), (4100, 8)):
         X, y, Xs = O.synthetic_problem(n, 8, 900 + n, m=2)
         out = []
-        for chain, first in ((0, 0), (1, 1), (1, 2), (3, 0), (0, 2)):
+        for chain, first in ((0, 0), (1, 1), (1, 2), (3, 0), (0, 2), (5, 1), (7, 2), (7, 0)):      # bit 2: the fused chain link (chain_link_kernel)
             with S.GPR(kernel=kern, outer_blocks=W, dtype=dtype) as gp:
                 gp.set_option("panel_chain", chain)
                 gp.set_option("first_on_panel", first)
@@ -407,12 +407,13 @@ def test_panel_chain_and_first_update_placement_are_schedules_only(S, dtype):
     for b in range(B):
         Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 170 + b, m=1)
     res = []
-    for chain, mode in ((0, "recursive"), (1, "recursive"), (3, "strips"), (0, "strips")):
+    for chain, mode in ((0, "recursive"), (1, "recursive"), (3, "strips"), (0, "strips"), (5, "recursive"), (7, "strips")):
         with S.GPR(kernel="rbf", outer_blocks=4, panel_mode=mode) as gp:
             gp.set_option("panel_chain", chain)
             res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
     for k in ("nlml", "mean", "var", "sigma_f"):
         assert np.array_equal(res[0][k], res[1][k]) and np.array_equal(res[2][k], res[3][k]), k
+        assert np.array_equal(res[0][k], res[4][k]) and np.array_equal(res[2][k], res[5][k]), k
 
 
 @pytest.mark.parametrize("kind", ["rbf", "matern52"])
