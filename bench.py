@@ -126,16 +126,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch one rank per GPU: python -m torch.distributed.run "
                          "--nproc-per-node %d bench.py --gpus %d ...)" % (args.gpus, world, args.gpus, args.gpus))
-    import torch
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    dist = None
+    # N = 1 runs on the HIP runtime the library links (/opt/rocm's) and never imports torch: the timed region is bracketed with the
+    # library's own sigp_synchronize.  torch is plumbing for N > 1 only (process group: barrier + max-reduce of the timing; it must be
+    # imported before the library there, see _lib.load).
+    torch = dist = None
     backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
-    if backend == "nccl" and world > torch.cuda.device_count():
-        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, torch.cuda.device_count()))
-    local = local % torch.cuda.device_count()
     if world > 1:
+        import torch
         import torch.distributed as dist
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+        if backend == "nccl" and world > torch.cuda.device_count():
+            raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (RCCL needs one GPU per rank)" % (world, torch.cuda.device_count()))
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
@@ -187,11 +190,16 @@ def main():
         r = gp.run_batch(0, W, ell[:W], sn[:W], concurrency=args.concurrency, group=args.group)
         assert np.all(r["info"] == 0)
 
+    def sync():
+        gp.synchronize()                     # hipDeviceSynchronize on the library's runtime ...
+        if torch is not None:
+            torch.cuda.synchronize()         # ... and, N > 1, on torch's view of the device (its collectives)
+
     def barrier():
-        torch.cuda.synchronize()
+        sync()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
     if not args.no_profile:
         gp.profile(True, classes=["syrk128"])      # the dominant kernel only: brackets inside the timed region
@@ -199,7 +207,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     r = gp.run_batch(W, K, ell[W:], sn[W:], concurrency=args.concurrency, group=args.group)
-    torch.cuda.synchronize()
+    sync()
     t1 = time.perf_counter()
     barrier()
     prof = gp.profile_get()
@@ -209,7 +217,7 @@ def main():
         # the same steps once more WITHOUT the per-launch HIP-event brackets of the dominant kernel (`value` carries them)
         barrier(); ta = time.perf_counter()
         gp.run_batch(W, K, ell[W:], sn[W:], concurrency=args.concurrency, group=args.group)
-        torch.cuda.synchronize(); tub = time.perf_counter() - ta
+        sync(); tub = time.perf_counter() - ta
         barrier()
         unbracketed = tub
     prof_all = None
@@ -228,9 +236,9 @@ def main():
         kk = min(K, 2 * args.group)
         gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
         gp.profile(True, classes=["syrk128"]); gp.profile_reset()
-        torch.cuda.synchronize(); ta = time.perf_counter()
+        sync(); ta = time.perf_counter()
         gp.run_batch(W, kk, ell[W:W + kk], sn[W:W + kk], concurrency=1, group=args.group)
-        torch.cuda.synchronize(); tu = time.perf_counter() - ta
+        sync(); tu = time.perf_counter() - ta
         pu = gp.profile_get()["syrk128"]; gp.profile(False)
         gp.set_option("strips_after_update", 0)
         if pu["ms"] > 0:
@@ -247,9 +255,9 @@ def main():
         gp.upload_batch(Xb, yb, Xs64, group=args.group, concurrency=args.concurrency)
         k64 = min(K, args.group)
         gp.run_batch(W, k64, ell[W:W + k64], sn[W:W + k64], concurrency=args.concurrency, group=args.group)
-        torch.cuda.synchronize(); ta = time.perf_counter()
+        sync(); ta = time.perf_counter()
         r64 = gp.run_batch(W, k64, ell[W:W + k64], sn[W:W + k64], concurrency=args.concurrency, group=args.group)
-        torch.cuda.synchronize(); tb64 = time.perf_counter() - ta
+        sync(); tb64 = time.perf_counter() - ta
         assert np.all(r64["info"] == 0) and np.all(np.isfinite(r64["var"]))
         m64 = {"value": k64 / tb64, "unit": "fits/s", "steps": k64, "note": "same workload with m=64 test points per fit (ride-along rows), measured after the timed region"}
     elapsed = t1 - t0
@@ -272,7 +280,7 @@ def main():
         "config": {"workload": "configs[2]: n=%d d=%d fp64 RBF GPR, batch of retrospective years x hyper-parameter grid (%s: %dx%d over l = sqrt(d) logspace(-1,1), sn~ = logspace(-3,1)), "
                                "one step = the %d years at one grid point factorised in lockstep, each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1"
                                % (n, d, args.grid, len(grid_axes(d, args.grid)[0]), len(grid_axes(d, args.grid)[1]), G),
-                   "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / max(1, fits // world if args.scaling == "weak" else fits), "years_resident_per_rank": len(my_years),
+                   "n": n, "d": d, "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / max(1, fits // world if args.scaling == "weak" else fits), "years_resident_per_rank": len(my_years),
                    "lockstep_group": args.group, "groups_in_flight": args.concurrency, "grid": args.grid,
                    "parallelism": ("years sharded over %d GPU(s): every rank its own %d years, no data-path collective" % (world, years)) if args.scaling == "weak" else
                                   ("the fixed %d-fit job dealt round-robin over %d GPU(s), no data-path collective" % (fits, world))},
@@ -336,6 +344,7 @@ def main():
             out["other_configs"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_reps"] = max(1, args.cpu_reps)
         cpu_baseline(out, args, Xb, yb, Xsb, ell, sn, W, len(my_years), r, local)
         if out.get("cpu_baseline", {}).get("value"):
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]     # (vs_baseline stays null: the reference publishes no number for this metric)
@@ -347,7 +356,7 @@ def main():
         def give_up():
             if rank == 0:
                 out["sharded"] = {"error": "no result within %.0f s (watchdog)" % args.sharded_timeout}
-                print(json.dumps(out), flush=True)
+                emit(out)
             os._exit(0)
 
         wd = threading.Timer(args.sharded_timeout, give_up)
@@ -361,9 +370,73 @@ def main():
         if rank == 0:
             out["sharded"] = rec
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def compact_line(out):
+    """The metric line the driver records (it keeps a 2 000-character tail): the contract's fields, `roofline`, `cpu_baseline`, the parity of
+    the timed step and one number per other BASELINE configuration -- at most 1.5 KB.  The full record goes to stderr and to
+    gpurun_out/bench_verbose.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    c = {k: out.get(k) for k in keep}
+    cfg = out.get("config", {})
+    c["config"] = {"workload": "configs[2]: n=%s d=%s fp64 RBF GPR, %s retrospective years x hyper-parameter grid, one step = the years at one grid point in lockstep"
+                               % (cfg.get("n"), cfg.get("d"), cfg.get("fits_per_step")),
+                   "fits_per_step": cfg.get("fits_per_step"), "grid": cfg.get("grid"), "parallelism": "years sharded over %s GPU(s), no data-path collective" % out.get("n_gpus")}
+    rf = out.get("roofline")
+    if rf:
+        c["roofline"] = {"bound": rf["bound"], "kernel": "syrk128_kernel<double> (trailing update, v_mfma_f64_16x16x4_f64)", "achieved": round(rf["achieved"], 3), "peak": rf["peak"],
+                         "unit": rf["unit"], "frac": round(rf["frac"], 4), "traffic": rf.get("traffic"), "avg_launch_ms": round(rf["avg_launch_ms"], 4), "launches": rf["launches"]}
+        if rf.get("unshared"):
+            c["roofline"]["unshared_frac"] = round(rf["unshared"]["frac"], 4)
+    else:
+        c["roofline"] = None
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "seconds": round(cb["seconds"], 2),
+                             "sample": "oracle in the reference's call sequence (north/June1st.py:264-277), n=%s, 1 warm-up + %s timed, median" % (cfg.get("n"), out.get("cpu_reps"))}
+        c["vs_cpu_baseline"] = round(out.get("vs_cpu_baseline", 0.0), 1)
+    if "parity" in out:
+        c["parity"] = {k: float("%.2e" % v) for k, v in out["parity"].items() if k.startswith("batch_step0")}
+    c["whole_fit_frac"] = round(out.get("whole_fit_frac_of_fp64_mfma_peak", 0.0), 4)
+    oc = out.get("other_configs") or {}
+    def ms(prefix, key="ms_per_fit"):
+        for k, v in oc.items():
+            if k.startswith(prefix) and isinstance(v, dict) and key in v:
+                return v
+        return None
+    for name, prefix in (("c1", "configs[1]"), ("c3", "configs[3]"), ("c4", "configs[4] n=")):
+        v = ms(prefix)
+        if v:
+            c[name + "_ms"] = round(v["ms_per_fit"], 3); c[name + "_frac"] = round(v["frac_of_peak"], 4)
+    v = ms("configs[4] shape, lockstep")
+    if v:
+        c["c4_group4_ms"] = round(v["ms_per_fit"], 2)
+    ml = oc.get("mlii", {})
+    for k, v in ml.items():
+        if k.startswith("n=8192 lockstep") and isinstance(v, dict):
+            c["mlii_g40_ms"] = round(v["ms_per_evaluation"], 3); c["mlii_g40_frac"] = round(v["frac_of_fp64_mfma_peak"], 4)
+    if "sharded" in out and isinstance(out["sharded"], dict):
+        c["sharded"] = {k: ({"ms_per_fit": round(v.get("ms_per_fit", 0.0), 3), "speedup_vs_1gpu": round(v.get("single_gpu", {}).get("speedup_of_sharded", 0.0), 3),
+                             "transport": str(v.get("transport"))[:40]} if isinstance(v, dict) and "ms_per_fit" in v else str(v)[:80]) for k, v in out["sharded"].items()}
+    c["verbose"] = "stderr; gpurun_out/bench_verbose.json"
+    return c
+
+
+def emit(out):
+    """Rank 0: the full record to stderr and gpurun_out/bench_verbose.json, then -- LAST, and the only line on stdout -- the compact metric line."""
+    txt = json.dumps(out)
+    print(txt, file=sys.stderr, flush=True)
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_verbose.json"), "w") as f:
+            f.write(txt + "\n")
+    except OSError:
+        pass
+    line = json.dumps(compact_line(out))
+    print(line, flush=True)
 
 
 def kernel_code_sha16():
@@ -473,7 +546,6 @@ def other_configs(local):
     """The other BASELINE configurations on ONE GPU (untimed extras, not the metric): latency of a single fit at
     configs[1] / [3] / [4] shape with its roofline fraction, the MLII (nlML + exact gradient) evaluation, and the
     reference's own kernel at the reference's own size batched over the 20x20 grid."""
-    import torch
     from seaiceextentforecasting_amd import GPR
     rec = {}
 
@@ -481,10 +553,10 @@ def other_configs(local):
         X, y, Xs = synthetic_problem(n, d, seed, m=1)
         with GPR(kernel=kernel, dtype=dtype, device=local) as g:
             g.fit(X, y, ell, sn, Xs=Xs)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+            g.synchronize(); t0 = time.perf_counter()
             for _ in range(reps):
                 g.refit(ell, sn)
-            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            g.synchronize(); dt = (time.perf_counter() - t0) / reps
             e = {"ms_per_fit": 1e3 * dt, "fits_per_s": 1.0 / dt, "tflops": flops_per_fit(n, d) / dt / 1e12,
                  "frac_of_peak": flops_per_fit(n, d) / dt / 1e12 / peak, "peak_tflops": peak, "note": "one fit at a time (latency), GPR.refit on resident data"}
             if dtype == "f32":
@@ -505,9 +577,9 @@ def other_configs(local):
             e4 = np.full(G4, np.sqrt(d4)); s4 = np.full(G4, 1e-1)
             g.upload_batch(Xb, yb, Xsb, group=G4, concurrency=1)
             g.run_batch(0, G4, e4, s4, concurrency=1, group=G4)
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+            g.synchronize(); t0 = time.perf_counter()
             r4 = g.run_batch(0, G4, e4, s4, concurrency=1, group=G4)
-            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / G4
+            g.synchronize(); dt = (time.perf_counter() - t0) / G4
         assert np.all(r4["info"] == 0)
         rec["configs[4] shape, lockstep group of 4 on one GPU"] = {"ms_per_fit": 1e3 * dt, "fits_per_s": 1.0 / dt, "tflops": flops_per_fit(n4, d4) / dt / 1e12,
                                                                  "frac_of_peak": flops_per_fit(n4, d4) / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, "peak_tflops": PEAK_F32_MFMA_TFLOPS}
@@ -522,10 +594,10 @@ def other_configs(local):
         with GPR(kernel="rbf", device=local) as g:
             g.set_data(X, y)
             g.nlml(th, grad="exact")
-            torch.cuda.synchronize(); t0 = time.perf_counter()
+            g.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
                 g.nlml(th, grad="exact")
-            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 3
+            g.synchronize(); dt = (time.perf_counter() - t0) / 3
             fl = mlii_flops(n, 8)
             ml["n=%d" % n] = {"ms": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
                               "algorithmic_flops": fl}
@@ -539,9 +611,9 @@ def other_configs(local):
             with GPR(kernel="rbf", device=local) as g:
                 g.upload_batch(Xb, yb, None, group=G, concurrency=1)
                 g.nlml_batch(th, grad="exact", group=G)
-                torch.cuda.synchronize(); t0 = time.perf_counter()
+                g.synchronize(); t0 = time.perf_counter()
                 g.nlml_batch(th, grad="exact", group=G)
-                torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / G
+                g.synchronize(); dt = (time.perf_counter() - t0) / G
             fl = mlii_flops(n, 8)
             ml["n=%d lockstep group of %d" % (n, G)] = {"ms_per_evaluation": 1e3 * dt, "tflops": fl / dt / 1e12, "frac_of_fp64_mfma_peak": fl / dt / 1e12 / PEAK_F64_MFMA_TFLOPS,
                                                       "evaluations_per_s": 1.0 / dt}
@@ -549,9 +621,9 @@ def other_configs(local):
                 # the optimiser the reference left commented out (north/June1st.py:259-262), for all 40 years at once: BFGS on (log l, log sn~)
                 # per year, ONE lockstep device call per round (GPR.optimize_batch)
                 with GPR(kernel="rbf", device=local) as g:
-                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    g.synchronize(); t0 = time.perf_counter()
                     ro = g.optimize_batch(Xb, yb, np.log([np.sqrt(8.0), 1e-1]), group=G, maxiter=30)
-                    torch.cuda.synchronize(); to = time.perf_counter() - t0
+                    g.synchronize(); to = time.perf_counter() - t0
                 ml["optimise 40 years, n=4096"] = {"seconds": to, "device_calls": int(ro["nfev"]), "iterations_per_year_mean": float(np.mean(ro["nit"])),
                                                    "converged_years": int(np.sum(ro["converged"])), "nlml_mean_at_optimum": float(np.mean(ro["fun"])),
                                                    "note": "includes the upload of the 40 data sets; every device call evaluates nlML + exact gradient for all 40 years in lockstep"}
@@ -568,7 +640,6 @@ def reference_kernel_grid(local):
     """The reference's OWN kernel at the reference's OWN size: the retro loop's 3 regions x 40 years
     (n = 6 .. 45 training years, N = 60 / 20 / 12 network areas) x the 20 x 20 grid of north/June1st.py:210-211 = 48 000 fits
     in ONE launch (one workgroup per fit), beside the oracle's loop over a sample of the same fits on the host."""
-    import torch
     from seaiceextentforecasting_amd import GPR, SmallBatch, LGRID, SGRID
     rng = np.random.default_rng(20240010)
     sets = []
@@ -589,11 +660,11 @@ def reference_kernel_grid(local):
         sb.upload()
         t_stage = time.perf_counter() - t0
         r = sb.run()                                   # warm-up
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        gp.synchronize(); t0 = time.perf_counter()
         reps = 3
         for _ in range(reps):
             r = sb.run()
-        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+        gp.synchronize(); dt = (time.perf_counter() - t0) / reps
     F = len(r["nlml"])
     flops = sum(400 * (n * n * N + n ** 3 / 3 + 4 * n * n) for (X, _, _) in sets for n, N in [X.shape])
     out = {"fits": F, "ok_fits": int(np.sum(r["info"] == 0)), "ms_per_launch": 1e3 * dt, "fits_per_s": F / dt, "host_staging_s": t_stage,

@@ -254,6 +254,10 @@ int sigp_profile(sigp_handle* h, int enable);
 int sigp_profile_get(sigp_handle* h, int kclass, double* total_ms, int64_t* launches, double* flops,
                      double* bytes);
 int sigp_profile_reset(sigp_handle* h);
+/* Wait for everything the handle's device has been given (hipDeviceSynchronize on the handle's device).  Every entry point above is
+ * synchronous on return already; a caller that brackets a timed region (bench.py) uses this for the bracket itself, so that the
+ * measurement runs on the HIP runtime the library links and needs no second one (PyTorch's) in the process. */
+int sigp_synchronize(sigp_handle* h);
 /* tuning knobs; returns SIGP_BAD_ARG for an unknown name or an invalid value.  Defaults in brackets.
  *   outer_blocks [8]      outer panel width in 128-column blocks (K of the trailing update = 128 x this)
  *   lookahead [1]         factor the next panel on the panel stream while the trailing update runs
@@ -266,12 +270,16 @@ int sigp_profile_reset(sigp_handle* h);
  *                         refinement's residuals read it (HBM-bound) instead of recomputing n^2 covariances each; 0 = recompute (no extra memory)
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
  *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
+ *   dist_timeout_ms [120000] deadline of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
+ *                         error / when it passes: ncclCommAbort, SIGP_HIP_ERROR (the panel reached is in sigp_last_error), the handle's sharded
+ *                         state is dead until sigp_dist_shutdown + a fresh sigp_dist_init* -- a dead peer is an error, not a hang; 0 = wait for ever
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:
  *   the trailing-update kernel's own rate, bench.py's roofline.unshared)
- *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [3] (bit 0: panels that are not strip-solved,
- *   bit 1: top blocks of strip-solved panels, are factored column by column with the other columns' update riding in the diagonal-block
- *   launch; 0 = binary recursion), chain_rows [80] (bit 0 applies while rows-below x members <= this), first_on_panel [1] (the update of
- *   the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always)
+ *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [15] (bit 0: panels that are not strip-solved,
+ *   bit 1: top blocks of strip-solved panels, are factored column by column with update work riding in the diagonal-block launches;
+ *   bit 2: ONE launch between two diagonal blocks (chain_link_kernel: what the next block needs, the column solve riding, every other update
+ *   riding in the next diagonal-block launch), bit 3: the binary recursion's two-column leaves take that form too; 0 = binary recursion), chain_rows [80] (bit 0 applies while rows-below x members <= this),
+ *   first_on_panel [1] (the update of the next panel's columns on the panel stream: 0 never, 1 for chain-form panels, 2 always)
  *   pan_priority, diag_prio, host_timing   measurement switches
  * The rejected experiments of DESIGN.md section 7 (xcd_chunks, update_wgs / update_late, pipeline_head / head_gate, wide_tiles, n64_tiles,
  * patch, small_nt64, reserve_cus, panel_ll, c_dma, syrk_v2) are compiled into libsigp_debug.so only (make debug; include/sigp_debug.h):

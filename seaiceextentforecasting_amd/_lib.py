@@ -63,6 +63,7 @@ SIGNATURES = {
     "sigp_profile": (C.c_int, [_h, C.c_int]),
     "sigp_profile_get": (C.c_int, [_h, C.c_int, _dp, C.POINTER(_i64), _dp, _dp]),
     "sigp_profile_reset": (C.c_int, [_h]),
+    "sigp_synchronize": (C.c_int, [_h]),
     "sigp_set_option": (C.c_int, [_h, C.c_char_p, _i64]),
 }
 

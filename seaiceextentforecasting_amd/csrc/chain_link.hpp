@@ -11,8 +11,9 @@
 //     rows of L[c+1, c] go to a SCRATCH block, not in place: the other workgroups of this launch still read the unsolved rows.
 //     (The diagonal-block launch that follows copies the scratch block into the matrix; its riding update of column c+1 reads it
 //     from the scratch.)
-//   * the other workgroups ("ride"): the column solve of the rows BELOW block row c+1, in place, on 32-row tiles -- the same tile
-//     code as the stand-alone solve launch (gemm_tile_body<32,128,GEMM_SET>).
+//   * the other workgroups ("ride"): the column solve of the rows BELOW block row c+1, in place, 16 rows per workgroup with the
+//     same triangular-skipping K loop (a quarter of the matrix instructions per wave of the stand-alone solve launch's 32-row tiles:
+//     the launch is over when its longest workgroup is).
 // The update of column c+1's rows below its diagonal block rides in the next diagonal-block launch with the panel's other columns.
 // Same operations on the same data in the same k order as the two launches it replaces: the factor is bit-identical (the products
 // with the inverse's structural zeros, which this kernel skips, add exact zeros).
@@ -39,7 +40,8 @@ struct LinkArgsT {
 
 template <typename T> constexpr int link_lds_bytes() { return gemm_lds_bytes<T, 32, LINK_NB, false>(); }
 
-template <typename T>
+// RIDE = false: chain workgroup t (tile (ti, tj) of block (c+1, c+1)).  RIDE = true: rows [16 t, 16 t + 16) below block row c+1, solved in place.
+template <typename T, bool RIDE>
 __device__ __forceinline__ void link_chain_body(const LinkArgsT<T>& a, int t, long bz, int tid, char* smem_raw) {
   typedef Num<T> N_;
   typedef typename N_::acc_t acc_t;
@@ -48,11 +50,12 @@ __device__ __forceinline__ void link_chain_body(const LinkArgsT<T>& a, int t, lo
   constexpr int NST = LINK_NB / KTe;   // K slices: 8 (fp64) / 4 (fp32)
   constexpr int PD = 4;                // slices in flight in registers
   static_assert(32 * LINK_LP * (int)sizeof(T) <= link_lds_bytes<T>(), "the image of the solved rows reuses the staging buffers");
-  __builtin_amdgcn_s_setprio(3);       // a link of the latency chain, usually beside MFMA-saturating update waves
+  __builtin_amdgcn_s_setprio(RIDE ? 2 : 3);   // a link of the latency chain, usually beside MFMA-saturating update waves
   int ti = 0;
-  while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-  const int tj = t - ti * (ti + 1) / 2;
-  const bool diag = ti == tj;
+  if (!RIDE) { while ((ti + 1) * (ti + 2) / 2 <= t) ++ti; }
+  const int tj = RIDE ? 0 : t - ti * (ti + 1) / 2;
+  if (RIDE) ti = LINK_NB / 16 + t;     // 16-row pieces counted from block row c+1
+  const bool diag = RIDE || ti == tj;  // (one row piece only)
   const T* Ag = a.Acol + bz * a.sM;
   const T* Bg = a.Linv + bz * a.sL;
   T* Cg = a.Cdiag + bz * a.sM + (long)(16 * ti) * a.ld + 16 * tj;
@@ -64,7 +67,7 @@ __device__ __forceinline__ void link_chain_body(const LinkArgsT<T>& a, int t, lo
   acc_t cacc;                          // wave 0: the tile of block (c+1, c+1), asked for first
 #pragma unroll
   for (int r = 0; r < 4; ++r) cacc[r] = (T)0;
-  if (wave == 0) {
+  if (!RIDE && wave == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) cacc[r] = Cg[(long)N_::drow(lq, r) * a.ld + lr];
   }
@@ -127,6 +130,16 @@ __device__ __forceinline__ void link_chain_body(const LinkArgsT<T>& a, int t, lo
   }
 #undef LINK_GLOAD
 #undef LINK_SSTORE
+  if (RIDE) {                          // in place: nobody else reads these rows in this launch
+    T* Og = a.Acol + bz * a.sM + (long)(16 * ti) * a.ld;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const int nt = c == 0 ? wave : 7 - wave;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Og[(long)N_::drow(lq, r) * a.ld + 16 * nt + lr] = acc[0][c][r];
+    }
+    return;
+  }
   // the tiles of block column 0 keep their row piece of L[c+1, c] for everyone after this launch
   if (tj == 0) {
     T* Sg = a.scratch + bz * a.sS + (long)(16 * ti) * LINK_NB;
@@ -161,16 +174,8 @@ template <typename T>
 __global__ __launch_bounds__(256, 2) void chain_link_kernel(LinkArgsT<T> a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int b = (int)blockIdx.x;
-  if (b < LINK_CHAIN_WGS) {
-    link_chain_body<T>(a, b, (long)blockIdx.y, (int)threadIdx.x, smem_raw);
-    return;
-  }
-  GemmArgsT<T> g{};                    // rows below block row c+1:  L[i, c] = A[i, c] inv(L_cc)^T, in place, 32-row tiles
-  g.A = a.Acol + (long)LINK_NB * a.ld; g.lda = a.ld; g.sA = a.sM;
-  g.B = a.Linv; g.ldb = LINK_NB; g.sB = a.sL;
-  g.C = a.Acol + (long)LINK_NB * a.ld; g.ldc = a.ld; g.sC = a.sM;
-  g.K = LINK_NB;
-  gemm_tile_body<T, 32, LINK_NB, 1, 4, GEMM_SET, false>(g, b - LINK_CHAIN_WGS, 0, (long)blockIdx.y, (int)threadIdx.x, smem_raw, true);
+  if (b < LINK_CHAIN_WGS) link_chain_body<T, false>(a, b, (long)blockIdx.y, (int)threadIdx.x, smem_raw);
+  else link_chain_body<T, true>(a, b - LINK_CHAIN_WGS, (long)blockIdx.y, (int)threadIdx.x, smem_raw);
 }
 
 }  // namespace sigp

@@ -10,6 +10,7 @@
 #include <functional>
 #include <limits>
 #include <mutex>
+#include <thread>
 #include <chrono>
 #include <string>
 #include <type_traits>
@@ -146,11 +147,15 @@ struct sigp_handle {
     double* alpha = nullptr; size_t cap_alpha = 0; double* pred = nullptr; size_t cap_pred = 0;
     long cap_ref_npad = 0;                     // order the fp64 refinement vectors (xq, rq, rpart, fpart) of a sharded fp32 fit are sized for
     double* dinfo = nullptr;                   // device scalar for the MIN all-reduce of the pivot info
+    bool dead = false;                         // a collective failed / timed out (dist_wait): every later sharded call fails until sigp_dist_shutdown
+    hipEvent_t ev_wait = nullptr;              // what dist_wait polls
+    int* prog = nullptr;                       // pinned host word: last panel the update stream got through (progress_kernel)
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
     double st_collectives = 0, st_host_comm_ms = 0, st_enqueue_ms = 0;
   } dc;
   int opt_dist_seg = 2;                        // sharded fit: column blocks per streamed broadcast segment (>= panel width: the panel travels whole)
+  long opt_dist_timeout_ms = 120000;           // deadline of every host-side wait of the sharded path (dist_wait); 0 = wait for ever
   int opt_dist_stats = 0;                      // time the broadcasts and the update stream's waits for them with HIP events
   int opt_owner_only = 0;                      // sigp_set_train does not allocate the full n x n slot matrix
   // state
@@ -181,11 +186,12 @@ struct sigp_handle {
   int opt_xcd_chunks = 0;    // > 0: trailing updates with >= 512 tiles walk their tiles in XCD-sized chunks of PxP patches (P = this value)
   int opt_first_on_panel = 1;        // right-looking + look-ahead: the update of the next panel's columns runs on the panel stream: 0 never,
                                      // 1 when that panel is a latency chain (not strip-solved: single fits, small groups), 2 always
-  int opt_panel_chain = 7;           // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
+  int opt_panel_chain = 15;          // latency-chain form of a panel (right-looking, column by column; only the next column's update is a launch of its
                                      // own, the other columns' update rides in the diagonal-block launch): bit 0 panels that are not strip-solved (single
                                      // fits, small groups), bit 1 the top block of strip-solved panels (lockstep batches); 0 = binary recursion;
                                      // bit 2: the chain's two small launches between two diagonal blocks (column solve, next column's update) are
-                                     // ONE launch that does only what the next diagonal block needs (chain_link_kernel), the rest rides
+                                     // ONE launch that does only what the next diagonal block needs (chain_link_kernel), the rest rides;
+                                     // bit 3: the binary recursion's leaf pairs (two columns) take that form too
   int opt_chain_rows = 80;           // (see panel_any)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_head_gate = 16;    // pipeline_head = 3: a group's tail begins when at most this many block columns remain behind the panel just enqueued
@@ -645,7 +651,7 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
       a.sM = matStride; a.sL = dinvStride; a.sS = (long)NB * NB;
       a.rows_ride = rows_below - 1;
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (2.0 * rows_below * NB * NB * NB + (double)NB * NB * NB), nb * 2.0 * rows_below * NB * NB * 8);
-      hipLaunchKernelGGL(chain_link_kernel<Real>, dim3((unsigned)(LINK_CHAIN_WGS + 4 * a.rows_ride), (unsigned)nb), dim3(256), link_lds_bytes<Real>(), sp, a);
+      hipLaunchKernelGGL(chain_link_kernel<Real>, dim3((unsigned)(LINK_CHAIN_WGS + 8 * a.rows_ride), (unsigned)nb), dim3(256), link_lds_bytes<Real>(), sp, a);
       HIPCHK(h, hipGetLastError());
     }
     GemmArgsT<Real> gu = upd_args(c, c + 1, 0, Wp - i - 1);    // columns c+1 .. J0+Wp-1 from row block c+2 down (block (c+1, c+1) is done)
@@ -758,6 +764,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       }
       return SIGP_OK;
     }
+    if (Wp == 2 && (h->opt_panel_chain & 8) && rlim - J0 >= 2)   // the recursion's leaf pairs through the fused link: D, link, D + riding update of the second column, solve
+      return chain_panel<Real>(h, s, sp, M, ld, matStride, dinvp, dinvStride, nb, J0, 2, rlim);
     const int hw = Wp / 2;
     int rc = panel_rec(J0, hw, rlim);
     if (rc) return rc;
@@ -771,9 +779,11 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   // top = the top block of a strip-solved panel.  A whole panel takes the chain form only while its riding updates (K = 128, 64x64
   // tiles: 4 flop per operand byte) stay shorter than the diagonal block they ride beside: up to chain_rows (80) 128-row blocks x
   // members below the panel's first column (n = 32768 in fp32 is 4 % faster with the recursion's K = 256 / 512 updates)
+  auto chain_form = [&](int J0, int Wp, int rlim, bool top) -> bool {
+    return Wp > 2 && (top ? (h->opt_panel_chain & 2) != 0 : ((h->opt_panel_chain & 1) != 0 && (long)(rlim - J0) * nb <= h->opt_chain_rows));
+  };
   auto panel_any = [&](int J0, int Wp, int rlim, bool top) -> int {
-    const bool chain = Wp > 2 && (top ? (h->opt_panel_chain & 2) != 0 : ((h->opt_panel_chain & 1) != 0 && (long)(rlim - J0) * nb <= h->opt_chain_rows));
-    return chain ? panel_chain(J0, Wp, rlim) : panel_rec(J0, Wp, rlim);
+    return chain_form(J0, Wp, rlim, top) ? panel_chain(J0, Wp, rlim) : panel_rec(J0, Wp, rlim);
   };
   // factor block columns [J0, J0+Wp): panel_top = everything on the panel stream up to the strip solve (the whole panel when it
   // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
@@ -1149,7 +1159,7 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const
 // =====================================================================================================
 extern "C" {
 
-int sigp_version(void) { return 300; }   // 3.0: the sharded fit inside the library (sigp_dist_init / _fit), sigp_runtime_info, sigp_nlml_grad_batch
+int sigp_version(void) { return 400; }   // 3.0: the sharded fit inside the library (sigp_dist_init / _fit), sigp_runtime_info, sigp_nlml_grad_batch
 
 // which HIP runtime serves this process (a process that also loads PyTorch-ROCm has two on disk; the first one mapped wins)
 int sigp_runtime_info(char* buf, int64_t len) {
@@ -1242,6 +1252,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "small_nt64")) { h->opt_small_nt64 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "dist_timeout_ms")) { if (value < 0) return SIGP_BAD_ARG; h->opt_dist_timeout_ms = (long)value; return SIGP_OK; }
   if (!strcmp(name, "dist_stats")) { h->opt_dist_stats = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_segment")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_dist_seg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
@@ -1257,7 +1268,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_stored")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_stored = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 7) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 15) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }
   if (!strcmp(name, "strips_after_update")) { h->opt_strips_after_update = value != 0; return SIGP_OK; }
   if (!strcmp(name, "pipeline_head")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_pipeline_head = (int)value; return SIGP_OK; }
   if (!strcmp(name, "head_gate")) { if (value < 0) return SIGP_BAD_ARG; h->opt_head_gate = (int)value; return SIGP_OK; }
@@ -2138,6 +2149,13 @@ int sigp_profile(sigp_handle* h, int enable) {
   if (!enable) prof_drain(h);
   // enable = 1: every class; otherwise a bit mask (bit k+8 = class k), e.g. (1 << (8 + SIGP_KC_SYRK128))
   h->prof = enable == 0 ? 0u : enable == 1 ? 0xffu : ((unsigned)enable >> 8) & 0xffu;
+  return SIGP_OK;
+}
+
+int sigp_synchronize(sigp_handle* h) {
+  if (!h) return SIGP_BAD_ARG;
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
   return SIGP_OK;
 }
 

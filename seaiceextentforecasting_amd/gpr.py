@@ -579,6 +579,11 @@ class GPR:
     def profile_reset(self):
         self._check(self._lib.sigp_profile_reset(self._h), "profile_reset")
 
+    def synchronize(self):
+        """Wait for everything the handle's device has been given (sigp_synchronize): the bracket of a timed region, on the
+        HIP runtime the library itself links."""
+        self._check(self._lib.sigp_synchronize(self._h), "synchronize")
+
     def profile_get(self):
         """{kernel class: dict(ms, launches, flops, bytes)} accumulated since the last reset."""
         out = {}

@@ -373,7 +373,7 @@ def test_rejected_experiments_are_not_in_the_product_library(S):
         for name in ("xcd_chunks", "update_wgs", "update_late", "pipeline_head", "wide_tiles", "n64_tiles", "patch", "small_nt64", "reserve_cus", "panel_ll"):
             with pytest.raises(ValueError, match="libsigp_debug"):
                 gp.set_option(name, 1)
-        for name, v in (("outer_blocks", 4), ("lookahead", 1), ("panel_chain", 3), ("first_on_panel", 1), ("strips_after_update", 0), ("schedule", 0)):
+        for name, v in (("outer_blocks", 4), ("lookahead", 1), ("panel_chain", 15), ("first_on_panel", 1), ("strips_after_update", 0), ("schedule", 0)):
             gp.set_option(name, v)
 
 
@@ -388,7 +388,7 @@ def test_panel_chain_and_first_update_placement_are_schedules_only(S, dtype):
     for n, W in ((2300, 8), (1100, 4), (700, 16), (4100, 8)):
         X, y, Xs = O.synthetic_problem(n, 8, 900 + n, m=2)
         out = []
-        for chain, first in ((0, 0), (1, 1), (1, 2), (3, 0), (0, 2), (5, 1), (7, 2), (7, 0)):      # bit 2: the fused chain link (chain_link_kernel)
+        for chain, first in ((0, 0), (1, 1), (1, 2), (3, 0), (0, 2), (5, 1), (7, 2), (15, 0), (8, 1)):      # bit 2: the fused chain link (chain_link_kernel)
             with S.GPR(kernel=kern, outer_blocks=W, dtype=dtype) as gp:
                 gp.set_option("panel_chain", chain)
                 gp.set_option("first_on_panel", first)

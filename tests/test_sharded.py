@@ -308,6 +308,63 @@ def test_config3_n16384_sharded_over_two_ranks(tmp_path):
     assert t_shard <= 1.10 * t_single, (t_single, t_shard)
 
 
+_C4_WORKER = r"""
+import os, sys, time
+import torch, torch.distributed as dist
+sys.path.insert(0, %(root)r)
+import numpy as np
+import seaiceextentforecasting_amd as S
+rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+z = np.load(%(fix)r)
+n, d, m = int(z["n"]), int(z["d"]), int(z["m"])
+rng = np.random.default_rng(int(z["seed"]))                    # oracle.gp_oracle.synthetic_problem, spelled out: the worker needs no oracle
+X = rng.standard_normal((n, d)); w = rng.standard_normal(d) / np.sqrt(d); y = np.sin(X @ w) + 0.1 * rng.standard_normal(n); Xs = rng.standard_normal((m, d))
+ell, sn = float(z["ell"]), float(z["sn"])
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+with S.DistributedGPR("matern52", rank, world, dist, device=0, outer_blocks=8, dtype="f32", stats=True) as dg:
+    t0 = time.perf_counter()
+    dg.fit(X, y, ell, sn, Xs=Xs)
+    mu, var = dg.predict(Xs)
+    assert 0.0 < dg.refine_residual_ <= 1e-10, (rank, dg.refine_residual_)
+    assert rel(mu, z["fmean"]) <= 1e-6 and rel(var, z["fvar"]) <= 1e-5, (rank, rel(mu, z["fmean"]), rel(var, z["fvar"]))
+    assert rel(dg.sigma_f_, z["sigma_f"]) <= 1e-6 and rel(dg.nlml_, z["nlml"]) <= 1e-5, (rank, rel(dg.sigma_f_, z["sigma_f"]), rel(dg.nlml_, z["nlml"]))
+    T = n // 128; mine = sum(8 for q in range(T // 8) if q %% world == rank)
+    assert abs(dg.matrix_bytes_ - (n + 128) * mine * 128 * 4) <= 8 * 128 * (n + 128) * 4, (dg.matrix_bytes_, mine)     # fp32, owner-only: within one panel of 2 GiB
+    Xn = np.random.default_rng(5).standard_normal((6, d))        # new points: sigp_dist_predict (collective) on the distributed fp32 factor
+    mu2, var2 = dg.predict(Xn)
+    print("rank", rank, "fit+predict %%.1f s" %% (time.perf_counter() - t0), "residual %%.2e" %% dg.refine_residual_, dg.stats(), flush=True)
+    np.savez(os.path.join(%(out)r, "pred_%%d.npz" %% rank), mu2=mu2, var2=var2, Xn=Xn, X=X if rank == 0 else 0, y=y if rank == 0 else 0)
+dist.barrier(); dist.destroy_process_group()
+open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_config4_n32768_fp32_sharded_over_two_ranks(tmp_path):
+    """BASELINE configs[4] at its stated size as ONE fit sharded over two ranks (host-pointer transport over gloo, both on the box's GPU):
+    n = 32768, d = 32, fp32 Matern-5/2, W = 8 -- fp32 owner-only storage, triangular solves on the DISTRIBUTED factor, fp64 residuals sharded
+    by rows -- against the oracle's numbers for exactly these inputs (tests/golden/config4_oracle.npz; no live oracle): mean <= 1e-6,
+    variance <= 1e-5, sigma_f <= 1e-6, nlML <= 1e-5, 0 < refinement residual <= 1e-10, per-rank matrix bytes within one panel of 2 GiB;
+    sigp_dist_predict at 6 new points against the single-GPU fp32 engine (mean <= 1e-6; variance <= 1e-3: an fp32 factor on both sides)."""
+    import seaiceextentforecasting_amd as S
+    fix = os.path.join(ROOT, "tests", "golden", "config4_oracle.npz")
+    script = tmp_path / "worker.py"
+    script.write_text(_C4_WORKER % dict(root=ROOT, out=str(tmp_path), fix=fix))
+    p = _torchrun(script, 2, 29950 + (os.getpid() % 40), 800)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert (tmp_path / "ok_0").exists() and (tmp_path / "ok_1").exists()
+    z0, z1 = np.load(tmp_path / "pred_0.npz"), np.load(tmp_path / "pred_1.npz")
+    assert np.array_equal(z0["mu2"], z1["mu2"]) and np.array_equal(z0["var2"], z1["var2"])       # the same numbers on every rank
+    z = np.load(fix)
+    with S.GPR(kernel="matern52", dtype="f32") as g1:
+        g1.fit(z0["X"], z0["y"], float(z["ell"]), float(z["sn"]))
+        m1, v1 = g1.predict(z0["Xn"])
+    rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+    assert rel(z0["mu2"], m1) <= 1e-6 and rel(z0["var2"], v1) <= 1e-3, (rel(z0["mu2"], m1), rel(z0["var2"], v1))
+
+
 # ---- the fully asynchronous path with REAL data movement, on one GPU --------------------------------------------------------------
 # The host-pointer transport synchronises per collective and a one-rank RCCL communicator moves nothing, so neither shows whether the
 # event choreography of the panel loop (segments leaving while the chain runs, buffer rotation, the next owner's segment updates)
@@ -316,7 +373,7 @@ def test_config3_n16384_sharded_over_two_ranks(tmp_path):
 # records an event on the library's stream and publishes (pointer, event); every other rank makes ITS stream wait for that event and
 # enqueues a device-to-device copy, then posts a copy-done event the root's stream waits for.  No stream is ever synchronised for a
 # broadcast: what RCCL does between GPUs, between handles.
-_ASYNC_WORKER = r'''
+_ASYNC_HEAD = r'''
 import ctypes as C, os, sys, threading, time
 sys.path.insert(0, %(root)r)
 import numpy as np
@@ -329,6 +386,10 @@ vp = C.c_void_p
 hip.hipEventCreateWithFlags.argtypes = [C.POINTER(vp), C.c_uint]; hip.hipEventRecord.argtypes = [vp, vp]
 hip.hipStreamWaitEvent.argtypes = [vp, vp, C.c_uint]; hip.hipMemcpyAsync.argtypes = [vp, vp, C.c_size_t, C.c_int, vp]
 hip.hipMemcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]; hip.hipStreamSynchronize.argtypes = [vp]
+HOSTFN = C.CFUNCTYPE(None, C.c_void_p)
+hip.hipLaunchHostFunc.argtypes = [vp, HOSTFN, vp]
+hip.hipHostMalloc.argtypes = [C.POINTER(vp), C.c_size_t, C.c_uint]
+hip.hipStreamWaitValue32.argtypes = [vp, vp, C.c_uint32, C.c_uint, C.c_uint32]; hip.hipEventSynchronize.argtypes = [vp]
 def chk(rc):
     if rc != 0:
         raise RuntimeError("hip error %%d" %% rc)
@@ -339,6 +400,7 @@ class Fabric:
         self.world, self.cv, self.slots = world, threading.Condition(), {}
         self.bar = threading.Barrier(world)
         self.red = [None] * world
+        self.ared = {}
     def slot(self, seq):
         with self.cv:
             return self.slots.setdefault(seq, {"root": None, "done": []})
@@ -355,19 +417,32 @@ class Rank:
     def bcast(self, ctx, buf, nbytes, root, stream):
         try:
             fab, sl = self.fab, self.fab.slot(self.seq); self.seq += 1
+            if getattr(fab, "poisoned", False):
+                return 1                                             # a transport that has failed on one rank fails on all (as an aborted communicator does)
+            if getattr(self, "fail_at", None) == self.seq:
+                with fab.cv:
+                    fab.poisoned = True; fab.cv.notify_all()
+                return 1
+            if getattr(self, "stall_at", None) == self.seq:          # the library's stream stalls for `stall_s` seconds (a peer that has stopped responding)
+                self.stall_cb = HOSTFN(lambda _p: time.sleep(self.stall_s))
+                chk(hip.hipLaunchHostFunc(stream, self.stall_cb, None))
             if self.seq %% 3 == self.rank %% 3:                         # uneven progress of the ranks' host threads
                 time.sleep(0.002 * ((self.seq * 7 + self.rank) %% 4))
             if self.rank == root:
                 ev = self.event(stream)                              # the panel / segment is complete on the library's stream here
                 with fab.cv:
                     sl["root"] = (buf, ev); fab.cv.notify_all()
-                    fab.cv.wait_for(lambda: len(sl["done"]) == fab.world - 1, timeout=120)
+                    fab.cv.wait_for(lambda: len(sl["done"]) == fab.world - 1 or getattr(fab, "poisoned", False), timeout=120)
+                    if getattr(fab, "poisoned", False):
+                        return 1
                     assert len(sl["done"]) == fab.world - 1
                 for d in sl["done"]:
                     chk(hip.hipStreamWaitEvent(stream, d, 0))        # the buffer may be reused once every copy out of it has run
             else:
                 with fab.cv:
-                    fab.cv.wait_for(lambda: sl["root"] is not None, timeout=120)
+                    fab.cv.wait_for(lambda: sl["root"] is not None or getattr(fab, "poisoned", False), timeout=120)
+                    if sl["root"] is None:
+                        return 1
                     src, ev = sl["root"]
                 chk(hip.hipStreamWaitEvent(stream, ev, 0))
                 chk(hip.hipMemcpyAsync(buf, src, nbytes, 3, stream))  # device to device
@@ -378,6 +453,8 @@ class Rank:
         except Exception as e:                                       # must not unwind through the C frames
             print("bcast callback failed:", repr(e), flush=True); return 1
     def allreduce(self, ctx, buf, count, is_f32, op, stream):       # a few hundred numbers at the end of a fit: through the host
+        if getattr(self, "async_red", False):
+            return self.allreduce_async(buf, count, is_f32, op, stream)
         try:
             fab = self.fab
             a = np.zeros(count, dtype=np.float32 if is_f32 else np.float64)
@@ -392,7 +469,46 @@ class Rank:
             return 0
         except Exception as e:
             print("allreduce callback failed:", repr(e), flush=True); return 1
+    def allreduce_async(self, buf, count, is_f32, op, stream):
+        """The same reduction with NOTHING waited for on the calling thread (what a device collective does): device -> pinned copy + an event, a
+        device-side wait on a flag word (hipStreamWaitValue32), pinned -> device copy.  A reducer thread per collective meets every rank's event,
+        reduces, writes the result into every rank's pinned buffer and raises the flags.  A rank whose stream is stalled never records its
+        event: the others' streams sit in their flag wait, and the library's own deadline (dist_wait) is what ends the call."""
+        try:
+            fab = self.fab
+            self.rseq = getattr(self, "rseq", 0) + 1
+            key = self.rseq
+            nbytes = count * (4 if is_f32 else 8)
+            pin = vp(); chk(hip.hipHostMalloc(C.byref(pin), nbytes + 64, 0))
+            arr = np.ctypeslib.as_array(C.cast(pin, C.POINTER(C.c_float if is_f32 else C.c_double)), shape=(count,))
+            flag = vp(pin.value + ((nbytes + 15) // 16) * 16)
+            C.cast(flag, C.POINTER(C.c_uint32))[0] = 0
+            chk(hip.hipMemcpyAsync(pin, buf, nbytes, 2, stream))
+            ev = self.event(stream)
+            chk(hip.hipStreamWaitValue32(stream, flag, 1, 1, 0xFFFFFFFF))      # == 1
+            chk(hip.hipMemcpyAsync(buf, pin, nbytes, 1, stream))
+            with fab.cv:
+                ent = fab.ared.setdefault(key, {})
+                ent[self.rank] = (ev, arr, flag)
+                start = len(ent) == fab.world
+            if start:                                                 # the last rank to post starts the reducer
+                def reducer(ent=ent, op=op):
+                    for r in range(fab.world):
+                        hip.hipEventSynchronize(ent[r][0])
+                    res = ent[0][1].copy()
+                    for r in range(1, fab.world):
+                        res = res + ent[r][1] if op == 0 else np.minimum(res, ent[r][1])
+                    for r in range(fab.world):
+                        ent[r][1][:] = res
+                        C.cast(ent[r][2], C.POINTER(C.c_uint32))[0] = 1
+                threading.Thread(target=reducer, daemon=True).start()
+            return 0
+        except Exception as e:
+            print("allreduce callback failed:", repr(e), flush=True); return 1
 
+'''
+
+_ASYNC_BODY = r'''
 rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
 world = %(world)d
 cases = [("rbf", "f64", 2100, 8, 2, 3, 1e-2), ("matern52", "f64", 1500, 5, 3, 2, 1e-2), ("rbf", "f64", 6000, 8, 8, 1, 1e-2), ("matern52", "f32", 2049, 16, 2, 2, 1e-1),
@@ -416,7 +532,9 @@ for kind, dtype, n, d, W, m, sn in cases:
             gp.set_data(X, y, Xs=Xs)
             res = []
             for rep in range(3):                                      # again and again on the same buffers: rotation and reuse under load
-                o4, mean, var = np.zeros(4), np.zeros(m), np.zeros(m)
+                if rep > 0 and rank == 1:
+                    time.sleep(0.03)                                  # rank 1 enters the refit LATE: panel 0's first segment is ready before its own build
+                o4, mean, var = np.zeros(4), np.zeros(m), np.zeros(m)     # has run (its panel stream must still wait for that build: ADVICE r3)
                 rc = lib.sigp_dist_fit(gp._h, gp._kid, ell, sn, None, 0, W, 1, L.ptr(o4), L.ptr(mean), L.ptr(var))
                 assert rc == 0, (rc, lib.sigp_last_error(gp._h))
                 res.append((o4.copy(), mean.copy(), var.copy()))
@@ -455,7 +573,79 @@ def test_sharded_fit_fully_asynchronous_device_transport(tmp_path, world):
     one process (one thread per rank, all on the box's GPU), device-pointer transport written with HIP events.  Three fits in a row
     per case on the same buffers; every rank and every repetition must give the same bits, == oracle."""
     script = tmp_path / "worker.py"
-    script.write_text(_ASYNC_WORKER % dict(root=ROOT, out=str(tmp_path), world=world))
+    script.write_text((_ASYNC_HEAD + _ASYNC_BODY) % dict(root=ROOT, out=str(tmp_path), world=world))
     p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=560)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert (tmp_path / "ok_async").exists()
+
+_DEAD_BODY = r'''
+rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+world = 2
+kind, n, d, W, m, sn = "rbf", 2100, 8, 2, 2, 1e-2
+X, y, Xs = O.synthetic_problem(n, d, 4711, m=m)
+ell = float(np.sqrt(d))
+ref = O.fit_predict(X, y, Xs, ell, sn, kind=kind, ref_idiom=False)
+
+def run_pair(inject):
+    # two handles, one thread each; returns per rank: (return codes of two consecutive sigp_dist_fit calls, last error, seconds, shutdown rc, result of a good fit)
+    fab = Fabric(world)
+    out = [None] * world
+    def run(rank):
+        rk = Rank(fab, rank)
+        rk.async_red = True                                          # nothing in this transport waits on the calling thread
+        if inject == "callback" and rank == 1:
+            rk.fail_at = 4                                           # its 4th broadcast returns 1
+        if inject == "stall" and rank == 1:
+            rk.stall_at, rk.stall_s = 4, 2.5                         # ... or stalls the stream for 2.5 s, far past the 400 ms deadline
+        gp = S.GPR(kernel=kind)
+        gp.set_option("owner_only", 1)
+        gp.set_option("dist_timeout_ms", 400 if inject == "stall" else 20000)
+        gp._check(lib.sigp_dist_init_transport(gp._h, world, rank, C.byref(rk.tr)), "dist_init_transport")
+        gp.set_data(X, y, Xs=Xs)
+        o4, mean, var = np.zeros(4), np.zeros(m), np.zeros(m)
+        t0 = time.perf_counter()
+        rc1 = lib.sigp_dist_fit(gp._h, gp._kid, ell, sn, None, 0, W, 1, L.ptr(o4), L.ptr(mean), L.ptr(var))
+        dt = time.perf_counter() - t0
+        err = lib.sigp_last_error(gp._h).decode()
+        rc2 = lib.sigp_dist_fit(gp._h, gp._kid, ell, sn, None, 0, W, 1, L.ptr(o4), L.ptr(mean), L.ptr(var)) if inject else 0
+        err2 = lib.sigp_last_error(gp._h).decode()
+        rcs = lib.sigp_dist_shutdown(gp._h)
+        gp.close()                                                   # sigp_destroy: must succeed on a dead handle (it waits for the stalled streams to drain)
+        out[rank] = dict(rc1=rc1, rc2=rc2, err=err, err2=err2, dt=dt, rcs=rcs, o4=o4.copy(), mean=mean.copy(), var=var.copy())
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ts: t.start()
+    for t in ts: t.join(120)
+    assert all(not t.is_alive() for t in ts), "a rank hangs"
+    return out
+
+for inject in ("callback", "stall"):
+    res = run_pair(inject)
+    for rank, r in enumerate(res):
+        assert r["rc1"] == L.HIP_ERROR, (inject, rank, r["rc1"], r["err"])                 # EVERY handle returns an error ...
+        assert "dead" in r["err"], (inject, rank, r["err"])
+        assert r["rc2"] == L.HIP_ERROR and "died in an earlier call" in r["err2"], (inject, rank, r["rc2"], r["err2"])
+        assert r["rcs"] == 0, (inject, rank)                                               # ... sigp_dist_shutdown / sigp_destroy succeed
+        assert r["dt"] < 10.0, (inject, rank, r["dt"])                                     # ... and nobody waits for long
+    if inject == "stall":
+        assert any("dist_timeout_ms" in r["err"] and "panel" in r["err"] for r in res), [r["err"] for r in res]   # the deadline, with the panel reached
+    print("ok", inject, [round(r["dt"], 3) for r in res], flush=True)
+    good = run_pair(None)                                                                   # fresh handles in the same process fit correctly
+    for rank, r in enumerate(good):
+        assert r["rc1"] == 0, (inject, rank, r["err"])
+        assert rel(r["mean"], ref["fmean"]) <= 1e-8 and rel(r["var"], ref["fvar"]) <= 1e-8 and rel(r["o4"][1], ref["nlml"]) <= 1e-9, (inject, rank)
+open(os.path.join(%(out)r, "ok_dead"), "w").write("ok")
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(400)
+def test_sharded_fit_dead_peer_is_an_error_not_a_hang(tmp_path):
+    """Transport-failure injection at world 2 (the asynchronous device transport, two handles in one process): (a) rank 1's 4th broadcast
+    callback returns 1, (b) it stalls the library's stream for 2.5 s with dist_timeout_ms = 400.  Every handle returns SIGP_HIP_ERROR within
+    seconds (no hang), says so again on the next call, sigp_dist_shutdown / sigp_destroy succeed, and fresh handles in the same process
+    fit correctly (== oracle).  The reference's convention: raise, don't hang (north/June1st.py:254-256)."""
+    script = tmp_path / "worker.py"
+    script.write_text((_ASYNC_HEAD + _DEAD_BODY) % dict(root=ROOT, out=str(tmp_path), world=2))
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=380)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert (tmp_path / "ok_dead").exists()
