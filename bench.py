@@ -493,13 +493,32 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 whole.append(float(t.item()))
             dg.gp.set_option("dist_segment", 2)
+            # ... and for the panel exchange by ROW PIECES + all-gather (dist_panel_split: the owner factors only the top block, every rank solves
+            # 1/world of the rows below it): the same bits, another critical path
+            dg.gp.set_option("dist_panel_split", 1)
+            dg.refit(ell, sn)
+            splitt = []
+            for r_ in range(reps):
+                torch.cuda.synchronize()
+                if dist is not None:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                dg.refit(ell, sn)
+                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                if dist is not None:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                splitt.append(float(t.item()))
+            st_split = dg.stats()
+            split_nlml = dg.nlml_
+            dg.gp.set_option("dist_panel_split", 0)
             dg.refit(ell, sn)
             mu, var = dg.predict(Xs)
             res = dict(sigma_f=dg.sigma_f_, nlml=dg.nlml_, mean=float(mu[0]), var=float(var[0]), matrix_bytes=dg.matrix_bytes_, transport=dg.transport)
             if dtype == "f32":
                 res["refinement_residual"] = dg.refine_residual_
         # per-rank numbers worth a max / sum over the ranks
-        v = torch.tensor([st["stall_ms"], st["comm_ms"], st["factor_ms"], st["solve_ms"], res["matrix_bytes"]], dtype=torch.float64, device=dev)
+        v = torch.tensor([st["stall_ms"], st["comm_ms"], st["factor_ms"], st["solve_ms"], res["matrix_bytes"], st["owner_ms"], st["link_bytes"], st_split["owner_ms"],
+                          st_split["link_bytes"], st_split["stall_ms"]], dtype=torch.float64, device=dev)
         vmax = v.clone()
         if dist is not None:
             dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
@@ -513,7 +532,14 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
              "max_over_ranks_ms": {"update_stream_stalled_on_a_panel": float(vmax[0]), "communication_window_first_segment_ready_to_last_arrived": float(vmax[1]), "panel_loop_device_time": float(vmax[2]),
                                    "reductions_solves_refinement_host_time": float(vmax[3])},
              "share_of_communication_window_with_update_work": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
-             "matrix_bytes_max_rank": float(vmax[4]), "sigma_f": res["sigma_f"], "nlml": res["nlml"], "mean": res["mean"], "var": res["var"]}
+             "matrix_bytes_max_rank": float(vmax[4]), "sigma_f": res["sigma_f"], "nlml": res["nlml"], "mean": res["mean"], "var": res["var"],
+             "panels": int(-(-(n // 128) // outer)),
+             "whole_panel_exchange": {"owner_only_ms_per_fit_max_rank": float(vmax[5]), "bytes_per_directed_link_per_fit_max_rank": float(vmax[6])},
+             "row_split_exchange": {"ms_per_fit": 1e3 * min(splitt), "ms_per_fit_all": [round(1e3 * t, 3) for t in splitt], "gain_over_streamed_segments": best / min(splitt),
+                                    "owner_only_ms_per_fit_max_rank": float(vmax[7]), "bytes_per_directed_link_per_fit_max_rank": float(vmax[8]),
+                                    "update_stream_stalled_ms_max_rank": float(vmax[9]), "split_panels": int(st_split["split_panels"]),
+                                    "bit_identical_nlml": bool(split_nlml == res["nlml"]),
+                                    "note": "dist_panel_split = 1: top block broadcast (8 MB at W = 8), rows below scattered in `world` pieces, solved where they land, all-gathered in place"}}
         if "refinement_residual" in res:
             e["refinement_residual"] = res["refinement_residual"]
         if rank == 0:

@@ -231,6 +231,11 @@ typedef struct sigp_transport {
   int (*bcast)(void* ctx, void* buf, uint64_t bytes, int root, void* stream);
   /* all-reduce `count` elements in place; is_f32: float, else double; op 0 = sum, 1 = min.  Non-zero return = failure. */
   int (*allreduce)(void* ctx, void* buf, uint64_t count, int is_f32, int op, void* stream);
+  /* Only for set_option("dist_panel_split", 1) (may be NULL otherwise), both in place on a buffer of nranks chunks of `chunk_bytes`:
+   * scatter: the root's chunk r goes to rank r at buf + r chunk_bytes (the root keeps its own);
+   * allgather: rank r contributes the chunk at buf + r chunk_bytes, every rank ends with all of them. */
+  int (*scatter)(void* ctx, void* buf, uint64_t chunk_bytes, int root, void* stream);
+  int (*allgather)(void* ctx, void* buf, uint64_t chunk_bytes, void* stream);
 } sigp_transport;
 int sigp_dist_unique_id(void* id128);
 int sigp_dist_init(sigp_handle* h, int nranks, int rank, const void* nccl_id);
@@ -270,6 +275,10 @@ int sigp_synchronize(sigp_handle* h);
  *                         refinement's residuals read it (HBM-bound) instead of recomputing n^2 covariances each; 0 = recompute (no extra memory)
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
  *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
+ *   dist_panel_split [0]  sharded fit, panel exchange by ROW PIECES ("all-gather of block-row pieces"): the owner factors only the panel's W x W top
+ *                         block and broadcasts it (8 MB at W = 8); the rows below it are scattered in `world` pieces, every rank solves its piece, and
+ *                         an in-place all-gather assembles the panel on every rank -- the owner's throughput work leaves the chain and each link carries
+ *                         1/world of the panel instead of all of it.  Rows are independent: results are bit-identical to dist_panel_split = 0.
  *   dist_timeout_ms [120000] deadline of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
  *                         error / when it passes: ncclCommAbort, SIGP_HIP_ERROR (the panel reached is in sigp_last_error), the handle's sharded
  *                         state is dead until sigp_dist_shutdown + a fresh sigp_dist_init* -- a dead peer is an error, not a hang; 0 = wait for ever

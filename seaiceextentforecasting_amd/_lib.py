@@ -119,10 +119,14 @@ def runtime_info():
 # the caller-supplied transport of the sharded fit (include/sigp.h: sigp_transport)
 BCAST_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_int, C.c_void_p)
+SCATTER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p)          # (ctx, buf, chunk_bytes, root, stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)                 # (ctx, buf, chunk_bytes, stream)
 
 
 class Transport(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("device_buffers", C.c_int), ("bcast", BCAST_FN), ("allreduce", ALLREDUCE_FN)]
+    """sigp_transport.  scatter / allgather are needed only for set_option("dist_panel_split", 1) and may stay NULL otherwise."""
+    _fields_ = [("ctx", C.c_void_p), ("device_buffers", C.c_int), ("bcast", BCAST_FN), ("allreduce", ALLREDUCE_FN), ("scatter", SCATTER_FN),
+                ("allgather", ALLGATHER_FN)]
 
 
 def ptr(a):

@@ -134,6 +134,8 @@ struct sigp_handle {
     void* hstage = nullptr; size_t cap_hstage = 0;   // pinned staging buffer of a host-pointer transport
     void* pbuf[2] = {nullptr, nullptr}; size_t cap_pbuf = 0;   // two row-major panel buffers in rotation (device)
     void* sbuf[2] = {nullptr, nullptr};                        // ... and two staging buffers of the streamed segments (same size)
+    void* tbuf[2] = {nullptr, nullptr}; size_t cap_tbuf = 0;   // row-split exchange: a panel's top block [W 128][W 128] + its W inverse diagonal blocks, in rotation
+    hipEvent_t ev_solve[2] = {nullptr, nullptr};               // ... this rank's row piece of the panel is solved (the all-gather waits for it)
     hipEvent_t ev_seg = nullptr;                               // a segment has arrived (next owner's panel stream waits for it)
     hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_first[2] = {nullptr, nullptr}, ev_mark = nullptr;
     std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
@@ -153,7 +155,12 @@ struct sigp_handle {
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
     double st_collectives = 0, st_host_comm_ms = 0, st_enqueue_ms = 0;
+    double st_link_bytes = 0, st_owner_ms = 0, st_split_panels = 0;   // bytes this rank sends to ONE peer per fit; device time of the owner-only work per fit; panels exchanged by row pieces
+    std::vector<hipEvent_t> ev_own;                                  // (pairs of stamps around the owner-only work of this rank's panels)
   } dc;
+  int opt_dist_split = 0;                      // sharded fit, panel exchange by ROW PIECES: the owner factors only the panel's W x W top block and broadcasts it; every rank
+                                               // solves 1/world of the rows below it (scattered to it) and an all-gather assembles the panel -- instead of one
+                                               // rank solving all rows and broadcasting the panel.  Same arithmetic per row: bit-identical results.
   int opt_dist_seg = 2;                        // sharded fit: column blocks per streamed broadcast segment (>= panel width: the panel travels whole)
   long opt_dist_timeout_ms = 120000;           // deadline of every host-side wait of the sharded path (dist_wait); 0 = wait for ever
   int opt_dist_stats = 0;                      // time the broadcasts and the update stream's waits for them with HIP events
@@ -1254,6 +1261,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_timeout_ms")) { if (value < 0) return SIGP_BAD_ARG; h->opt_dist_timeout_ms = (long)value; return SIGP_OK; }
   if (!strcmp(name, "dist_stats")) { h->opt_dist_stats = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "dist_panel_split")) { h->opt_dist_split = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_segment")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_dist_seg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }
@@ -2129,7 +2137,8 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
   const struct { const char* nm; const double* v; } ds[] = {
       {"dist_fit_ms", &h->dc.st_fit_ms}, {"dist_factor_ms", &h->dc.st_factor_ms}, {"dist_bcast_bytes", &h->dc.st_bcast_bytes}, {"dist_comm_ms", &h->dc.st_comm_ms},
       {"dist_stall_ms", &h->dc.st_stall_ms}, {"dist_solve_ms", &h->dc.st_solve_ms}, {"dist_collectives", &h->dc.st_collectives},
-      {"dist_host_comm_ms", &h->dc.st_host_comm_ms}, {"dist_enqueue_ms", &h->dc.st_enqueue_ms}};
+      {"dist_host_comm_ms", &h->dc.st_host_comm_ms}, {"dist_enqueue_ms", &h->dc.st_enqueue_ms}, {"dist_link_bytes", &h->dc.st_link_bytes},
+      {"dist_owner_ms", &h->dc.st_owner_ms}, {"dist_split_panels", &h->dc.st_split_panels}};
   for (const auto& e : ds)
     if (!strcmp(name, e.nm)) { *value = *e.v; return SIGP_OK; }
   if (!strcmp(name, "dist_comm_ranks")) {        // what the communicator itself reports (ncclCommCount); 0 = no RCCL communicator on this handle

@@ -122,7 +122,8 @@ class DistributedGPR:
     Same call sites as ``GPR``: ``fit`` (north/June1st.py:264-271) and ``predict`` (:272-277); the factor stays spread over
     the ranks, so predictions exist for the points passed to ``fit(Xs=...)`` (they ride along the factorisation)."""
 
-    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=8, lookahead=True, dtype="f64", owner_only=True, stats=False, force_rccl=False):
+    def __init__(self, kernel, rank, world, dist, device=0, outer_blocks=8, lookahead=True, dtype="f64", owner_only=True, stats=False, force_rccl=False,
+                 panel_split=False):
         from .gpr import GPR
         self.rank, self.world, self.dist = int(rank), int(world), dist
         self.W = int(outer_blocks)
@@ -133,6 +134,8 @@ class DistributedGPR:
         self.gp.set_option("owner_only", 1)
         if stats:
             self.gp.set_option("dist_stats", 1)
+        if panel_split:                        # panel exchange by row pieces + all-gather (sigp.h: dist_panel_split); bit-identical results
+            self.gp.set_option("dist_panel_split", 1)
         self.device = device
         self.transport = "none"
         self._force_rccl = bool(force_rccl)    # world == 1 only: open a one-rank RCCL communicator anyway (exercises the RCCL path on one GPU)
@@ -205,8 +208,35 @@ class DistributedGPR:
             except Exception:            # noqa: BLE001
                 return 1
 
-        self._cb = (L.BCAST_FN(bcast), L.ALLREDUCE_FN(allreduce))
-        self._tr = L.Transport(None, 0, self._cb[0], self._cb[1])
+        world, rank = self.world, self.rank
+
+        def scatter(ctx, buf, chunk, root, stream):          # in place: the root's chunk r -> rank r at buf + r chunk
+            try:
+                full = as_tensor(buf, int(chunk) * world, np.uint8)
+                parts = [full[r * int(chunk):(r + 1) * int(chunk)] for r in range(world)]
+                mine = torch.empty(int(chunk), dtype=torch.uint8)
+                dist.scatter(mine, [q.clone() for q in parts] if rank == int(root) else None, src=int(root))
+                if rank != int(root):
+                    parts[rank].copy_(mine)
+                return 0
+            except Exception:            # noqa: BLE001
+                return 1
+
+        def allgather(ctx, buf, chunk, stream):              # in place: chunk r from rank r
+            try:
+                full = as_tensor(buf, int(chunk) * world, np.uint8)
+                parts = [full[r * int(chunk):(r + 1) * int(chunk)] for r in range(world)]
+                got = [torch.empty(int(chunk), dtype=torch.uint8) for _ in range(world)]
+                dist.all_gather(got, parts[rank].clone())
+                for r in range(world):
+                    if r != rank:
+                        parts[r].copy_(got[r])
+                return 0
+            except Exception:            # noqa: BLE001
+                return 1
+
+        self._cb = (L.BCAST_FN(bcast), L.ALLREDUCE_FN(allreduce), L.SCATTER_FN(scatter), L.ALLGATHER_FN(allgather))
+        self._tr = L.Transport(None, 0, self._cb[0], self._cb[1], self._cb[2], self._cb[3])
         gp = self.gp
         gp._check(gp._lib.sigp_dist_init_transport(gp._h, self.world, self.rank, C.byref(self._tr)), "dist_init_transport")
         self.transport = "host"
@@ -274,7 +304,8 @@ class DistributedGPR:
 
     def stats(self):
         """``dist_*`` statistics of the last fit (meaningful with ``stats=True``): ms and bytes on THIS rank."""
-        return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks", "host_comm_ms", "enqueue_ms")}
+        return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks", "host_comm_ms", "enqueue_ms",
+                                                                "link_bytes", "owner_ms", "split_panels")}
 
     def predict(self, Xs):
         """(fmean [m], fvar [m]) as ``GPR.predict``.  The points passed to ``fit(Xs=...)`` rode along the factorisation and cost nothing;

@@ -39,15 +39,15 @@ def test_tcp_rendezvous_hands_the_same_id_to_every_rank():
 
 
 def test_transport_struct_matches_the_header():
-    """sigp_transport of include/sigp.h <-> _lib.Transport: four pointer-sized / int fields in the declared order."""
+    """sigp_transport of include/sigp.h <-> _lib.Transport: six pointer-sized / int fields in the declared order."""
     import ctypes as C
     from seaiceextentforecasting_amd import _lib as L
     names = [f[0] for f in L.Transport._fields_]
-    assert names == ["ctx", "device_buffers", "bcast", "allreduce"]
-    assert C.sizeof(L.Transport) == 4 * C.sizeof(C.c_void_p)          # int padded to pointer alignment
+    assert names == ["ctx", "device_buffers", "bcast", "allreduce", "scatter", "allgather"]
+    assert C.sizeof(L.Transport) == 6 * C.sizeof(C.c_void_p)          # int padded to pointer alignment
     hdr = open(os.path.join(ROOT, "include", "sigp.h")).read()
     body = hdr[hdr.index("typedef struct sigp_transport {"):hdr.index("} sigp_transport;")]
-    order = [body.index(k) for k in ("void* ctx;", "int device_buffers;", "(*bcast)", "(*allreduce)")]
+    order = [body.index(k) for k in ("void* ctx;", "int device_buffers;", "(*bcast)", "(*allreduce)", "(*scatter)", "(*allgather)")]
     assert order == sorted(order)
 
 
@@ -114,6 +114,22 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
             dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
             assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
     assert np.array_equal(bits[0][0], bits[1][0]) and np.array_equal(bits[0][1], bits[1][1]) and bits[0][2] == bits[1][2], "look-ahead changed the bits"
+    # the panel exchange by ROW PIECES (dist_panel_split): top block broadcast, the rows below scattered / solved where they land / all-gathered.
+    # Rows are independent: the same bits, with and without look-ahead; later predictions at new points read the factor in the owners' storage
+    for la in (True, False):
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la, stats=True, panel_split=True) as dg:
+            dg.fit(X, y, ell, sn, Xs=Xs)
+            mu, var = dg.predict(Xs)
+            assert np.array_equal(mu, bits[0][0]) and np.array_equal(var, bits[0][1]) and dg.nlml_ == bits[0][2], (kind, n, W, la, "row-split panel exchange changed the bits")
+            st = dg.stats()
+            T = -(-n // 128)
+            if world > 1 and T + 1 - W >= 2 * world:
+                assert st["split_panels"] >= 1, st
+            if kind != "netdiffusion":
+                Xn = np.vstack([Xs[:2] + 0.25, np.random.default_rng(n).standard_normal((5, d))])
+                mu2, var2 = dg.predict(Xn)
+                ref2 = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
+                assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la, "split", rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]))
     # the streamed broadcast: segments of 1 / 3 column blocks and whole panels -- the next owner then applies K = 128 / 384 / W 128
     # updates instead of K = 256 ones: same k order per tile, so the same bits
     for seg in (1, 3, 64):
@@ -147,6 +163,12 @@ for kind, n, d, W, m in (("matern52", 900, 16, 2, 2), ("rbf", 2049, 32, 3, 3), (
             T = -(-n // 128); P = -(-T // W)
             mine = sum(min(W, T - q * W) for q in range(P) if q %% world == rank)
             assert abs(dg.matrix_bytes_ - (T * 128 + 128) * max(mine * 128, 128) * 4) <= 4 * 128 * 128 * 8, (dg.matrix_bytes_, mine)   # fp32: half the bytes, ~ 1/world
+            keep = (dg.sigma_f_, dg.nlml_, None if not m else (mu.copy(), var.copy()), mu2.copy(), var2.copy())
+        with S.DistributedGPR(kind, rank, world, dist, device=0, outer_blocks=W, lookahead=la, dtype="f32", panel_split=True) as dg:
+            dg.fit(X, y, ell, sn, Xs=Xs)                     # fp32 panels exchanged by row pieces: the same bits again
+            assert dg.sigma_f_ == keep[0] and dg.nlml_ == keep[1], (kind, n, rank, la, "fp32 row-split changed the bits")
+            mu2b, var2b = dg.predict(Xn)
+            assert np.array_equal(mu2b, keep[3]) and np.array_equal(var2b, keep[4])
 # the full ride block (127 test points) through the sharded fit; sigp_dist_predict refuses to run before a fit
 X, y, Xs = O.synthetic_problem(700, 6, 98, m=127)
 ref = O.fit_predict(X, y, Xs, 2.0, 1e-2, kind="rbf", ref_idiom=False)
@@ -269,6 +291,15 @@ with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=8, stats=
     n = X.shape[0]; T = n // 128; mine = sum(8 for q in range(T // 8) if q %% world == rank)
     assert abs(dg.matrix_bytes_ - (n + 128) * mine * 128 * 8) <= 4 * 128 * 128 * 8        # ~ 1/world of 2 GiB
     print("rank", rank, dg.stats(), flush=True)
+    keep = (mu.copy(), var.copy(), dg.nlml_, dg.stats())
+with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=8, stats=True, panel_split=True) as dg:
+    dg.fit(X, y, float(z["ell"]), float(z["sn"]), Xs=Xs)     # the same fit with the panels exchanged by row pieces + all-gather: the same bits
+    mu, var = dg.predict(Xs)
+    assert np.array_equal(mu, keep[0]) and np.array_equal(var, keep[1]) and dg.nlml_ == keep[2], (rank, "row-split panel exchange changed the bits")
+    st = dg.stats()
+    assert st["split_panels"] >= 10, st
+    assert st["link_bytes"] < 0.75 * keep[3]["link_bytes"] or rank != 0, (st["link_bytes"], keep[3]["link_bytes"])     # an owner's links carry pieces, not whole panels
+    print("rank", rank, "row-split", st, flush=True)
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")
 '''
@@ -409,8 +440,8 @@ class Rank:
     def __init__(self, fab, rank):
         self.fab, self.rank, self.seq = fab, rank, 0
         self.events = []
-        self.cb = (L.BCAST_FN(self.bcast), L.ALLREDUCE_FN(self.allreduce))
-        self.tr = L.Transport(None, 1, self.cb[0], self.cb[1])       # device_buffers = 1
+        self.cb = (L.BCAST_FN(self.bcast), L.ALLREDUCE_FN(self.allreduce), L.SCATTER_FN(self.scatter), L.ALLGATHER_FN(self.allgather))
+        self.tr = L.Transport(None, 1, self.cb[0], self.cb[1], self.cb[2], self.cb[3])       # device_buffers = 1
     def event(self, stream):
         e = vp(); chk(hip.hipEventCreateWithFlags(C.byref(e), 2)); chk(hip.hipEventRecord(e, stream)); self.events.append(e)
         return e
@@ -452,6 +483,54 @@ class Rank:
             return 0
         except Exception as e:                                       # must not unwind through the C frames
             print("bcast callback failed:", repr(e), flush=True); return 1
+    def scatter(self, ctx, buf, chunk, root, stream):               # in place: the root's chunk r -> rank r (row-split panel exchange)
+        try:
+            fab, sl = self.fab, self.fab.slot(self.seq); self.seq += 1
+            if self.rank == root:
+                ev = self.event(stream)
+                with fab.cv:
+                    sl["root"] = (buf, ev); fab.cv.notify_all()
+                    fab.cv.wait_for(lambda: len(sl["done"]) == fab.world - 1, timeout=120)
+                    assert len(sl["done"]) == fab.world - 1
+                for d in sl["done"]:
+                    chk(hip.hipStreamWaitEvent(stream, d, 0))
+            else:
+                with fab.cv:
+                    fab.cv.wait_for(lambda: sl["root"] is not None, timeout=120)
+                    src, ev = sl["root"]
+                chk(hip.hipStreamWaitEvent(stream, ev, 0))
+                off = self.rank * chunk
+                chk(hip.hipMemcpyAsync(buf + off, src + off, chunk, 3, stream))
+                d = self.event(stream)
+                with fab.cv:
+                    sl["done"].append(d); fab.cv.notify_all()
+            return 0
+        except Exception as e:
+            print("scatter callback failed:", repr(e), flush=True); return 1
+    def allgather(self, ctx, buf, chunk, stream):                   # in place: chunk r from rank r, every rank ends with all of them
+        try:
+            fab, sl = self.fab, self.fab.slot(self.seq); self.seq += 1
+            if self.seq %% 2 == self.rank %% 2:
+                time.sleep(0.001)                                    # uneven host progress
+            ev = self.event(stream)                                  # my chunk is solved here
+            with fab.cv:
+                sl.setdefault("pub", {})[self.rank] = (buf, ev); fab.cv.notify_all()
+                fab.cv.wait_for(lambda: len(sl["pub"]) == fab.world, timeout=120)
+                pub = dict(sl["pub"])
+            for q, (src, evq) in pub.items():
+                if q != self.rank:
+                    chk(hip.hipStreamWaitEvent(stream, evq, 0))
+                    chk(hip.hipMemcpyAsync(buf + q * chunk, src + q * chunk, chunk, 3, stream))
+            d = self.event(stream)                                   # I have read everybody's chunk
+            with fab.cv:
+                sl["done"].append(d); fab.cv.notify_all()
+                fab.cv.wait_for(lambda: len(sl["done"]) == fab.world, timeout=120)
+                done = list(sl["done"])
+            for e in done:
+                chk(hip.hipStreamWaitEvent(stream, e, 0))            # my chunk may be overwritten once everybody has read it
+            return 0
+        except Exception as e:
+            print("allgather callback failed:", repr(e), flush=True); return 1
     def allreduce(self, ctx, buf, count, is_f32, op, stream):       # a few hundred numbers at the end of a fit: through the host
         if getattr(self, "async_red", False):
             return self.allreduce_async(buf, count, is_f32, op, stream)
@@ -531,7 +610,8 @@ for kind, dtype, n, d, W, m, sn in cases:
             gp._check(lib.sigp_dist_init_transport(gp._h, world, rank, C.byref(rk.tr)), "dist_init_transport")
             gp.set_data(X, y, Xs=Xs)
             res = []
-            for rep in range(3):                                      # again and again on the same buffers: rotation and reuse under load
+            for rep in range(5):                                      # again and again on the same buffers: rotation and reuse under load
+                gp.set_option("dist_panel_split", 1 if rep >= 3 else 0)   # the last two: panel exchange by row pieces + all-gather -- the same bits
                 if rep > 0 and rank == 1:
                     time.sleep(0.03)                                  # rank 1 enters the refit LATE: panel 0's first segment is ready before its own build
                 o4, mean, var = np.zeros(4), np.zeros(m), np.zeros(m)     # has run (its panel stream must still wait for that build: ADVICE r3)
