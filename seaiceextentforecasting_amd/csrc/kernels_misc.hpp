@@ -148,6 +148,106 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
   }
 }
 
+// The same tiles with the squared distances in GEMM form on the matrix pipe (SURVEY 8d counts the build that way):
+//     |x_i - x_j|^2 = |x_i|^2 + |x_j|^2 - 2 x_i . x_j,      the inner products by v_mfma_f64_16x16x4_f64
+// from LDS images of the tile's 64 + 128 rows of X (feature chunks of DC).  kbuild_kernel spends 2 d fp64 VALU instructions per element
+// on the distance (d = 32: 64 of its ~95) while the matrix pipe idles; here the VALU keeps the covariance function and three adds, and
+// the kernel is left with its stores.  Wave w owns tile rows 16 w .. 16 w + 15 and all eight 16-column tiles; the column operand is fed
+// in the order sigma(i) = 4 (i mod 4) + i div 4, so that a lane's four accumulator registers (rows lq + 4 r of the MFMA result) are FOUR
+// CONSECUTIVE COLUMNS 4 lq .. 4 lq + 3 of matrix row lr: one 32-byte (fp64) / 16-byte (fp32) store per lane and tile, a whole 128-byte
+// line per matrix row and wave instruction.  Rounding: the Gram form loses relative accuracy for near-coincident points, not absolute:
+// |error(sq)| <~ 4 eps max(|x_i|^2, |x_j|^2), i.e. <= 1e-15 d in K~ at the synthetic workloads' scales (K~ tolerance 1e-13); the diagonal
+// is exact (sq = 0 by construction), sq is clamped at 0.
+template <typename TO, int DC>
+__global__ __launch_bounds__(256) void kbuild_mfma_kernel(const double* __restrict__ X, long strideX, int dp, int d, int n,
+                                                          TO* __restrict__ Mat, long strideM, long ld,
+                                                          const KParams* __restrict__ kps, int flags_in, int colblk0 = 0,
+                                                          double* __restrict__ Mat64 = nullptr, long stride64 = 0) {
+  const int flags = flags_in & (DBG_MASK | 1 | 8 | 16);
+  const int full = flags & 1;
+  int bi, bj;
+  long mcol = -1;
+  if (flags & 16) {                // (tile selection exactly as kbuild_kernel)
+    const int W = colblk0 & 255, world = (colblk0 >> 8) & 255, rank = (colblk0 >> 16) & 255;
+    bi = blockIdx.y;
+    bj = ((int)blockIdx.x / W * world + rank) * W + (int)blockIdx.x % W;
+    if (bi * KB_TM + KB_TM <= bj * KB_TN) return;
+    mcol = (long)blockIdx.x * KB_TN;
+  } else if (flags & 8) {
+    bi = blockIdx.y; bj = colblk0 + blockIdx.x;
+    if (bi * KB_TM + KB_TM <= bj * KB_TN) return;
+  } else if (full) {
+    bi = blockIdx.y; bj = blockIdx.x;
+  } else {
+    const int u = blockIdx.x >> 1;
+    int k = (int)((sqrt(8.0 * u + 1.0) - 1.0) * 0.5);
+    while ((k + 1) * (k + 2) / 2 <= u) ++k;
+    while (k * (k + 1) / 2 > u) --k;
+    bj = u - k * (k + 1) / 2;
+    bi = 2 * k + (blockIdx.x & 1);
+  }
+  const KParams kp = kps[blockIdx.z];
+  X += kp.ds * strideX;
+  Mat += blockIdx.z * strideM;
+  constexpr int LP = DC + 2;                                       // conflict-free 8-byte fragment reads (row = lane & 15, k = lane >> 4)
+  __shared__ __attribute__((aligned(16))) double Xi[KB_TM * LP];
+  __shared__ __attribute__((aligned(16))) double Xj[KB_TN * LP];
+  __shared__ __attribute__((aligned(16))) double nI[KB_TM], nJ[KB_TN];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lq = lane >> 4;
+  const int dq = (d + 3) & ~3;                                     // (X is zero-padded to dp >= dq features)
+  if (tid < KB_TM + KB_TN) {                                       // squared norms of the tile's rows, one thread per row
+    const double* xr = X + (long)(tid < KB_TM ? bi * KB_TM + tid : bj * KB_TN + tid - KB_TM) * dp;
+    double sacc = 0.0;
+    for (int p = 0; p < dq; p += 2) { const d2 v = *(const d2*)(xr + p); sacc = fma(v.x, v.x, sacc); sacc = fma(v.y, v.y, sacc); }
+    if (tid < KB_TM) nI[tid] = sacc; else nJ[tid - KB_TM] = sacc;
+  }
+  d4 acc[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[t][r] = 0.0;
+  const int sig = 4 * (lr & 3) + (lr >> 2);                        // the column fed as MFMA row lr
+  for (int p0 = 0; p0 < dq; p0 += DC) {
+    const int pc = min(DC, dq - p0);                               // multiple of 4
+    __syncthreads();
+    for (int idx = tid; idx < (KB_TM + KB_TN) * (pc >> 1); idx += 256) {      // 16-byte pieces, lanes along the features of a row
+      const int row = idx / (pc >> 1), q = (idx - row * (pc >> 1)) * 2;
+      const d2 v = *(const d2*)(X + (long)(row < KB_TM ? bi * KB_TM + row : bj * KB_TN + row - KB_TM) * dp + p0 + q);
+      double* dst = row < KB_TM ? Xi + row * LP + q : Xj + (row - KB_TM) * LP + q;
+      *(d2*)dst = v;
+    }
+    __syncthreads();
+    const double* bI = Xi + (16 * wave + lr) * LP + lq;
+    const double* aJ = Xj + sig * LP + lq;
+    for (int kk = 0; kk < pc; kk += 4) {
+      const double b = bI[kk];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aJ[16 * t * LP + kk], b, acc[t], 0, 0, 0);
+    }
+  }
+  const int gi = bi * KB_TM + 16 * wave + lr;
+  const double ni = nI[16 * wave + lr];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int gj = bj * KB_TN + 16 * t + 4 * lq;
+    const d2 nj01 = *(const d2*)(nJ + 16 * t + 4 * lq), nj23 = *(const d2*)(nJ + 16 * t + 4 * lq + 2);
+    const double njv[4] = {nj01.x, nj01.y, nj23.x, nj23.y};
+    KbOut4<TO> o;
+    KbOut4<double> o64;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double sq = fmax(fma(-2.0, acc[t][c], ni + njv[c]), 0.0);
+      if (gi == gj + c) sq = 0.0;
+      double v;
+      if (gi >= n) v = (gi == gj + c && !full) ? 1.0 : 0.0;
+      else v = (gj + c < n) ? ((flags & 2) ? sq : cov_from_sq(kp, sq)) + (gi == gj + c ? kp.sn : 0.0) : 0.0;
+      o.v[c] = (TO)v; o64.v[c] = v;
+    }
+    if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + (mcol >= 0 ? mcol + 16 * t + 4 * lq : (long)gj)) = o;
+    if (Mat64 != nullptr) *(KbOut4<double>*)(Mat64 + blockIdx.z * stride64 + (long)gi * ld + gj) = o64;
+  }
+}
+
 // Ride-along block (128 rows x n_pad): row 0 = y (may be null -> zeros), rows 1..m = k~(xs_j, x_i)
 // (north/June1st.py:272 KXXs^T in unit signal variance), remaining rows 0.  first_row lets predict()
 // fill rows 0..m-1 with cross-covariances only (y == nullptr, first_row = 0).

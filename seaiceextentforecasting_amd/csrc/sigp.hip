@@ -183,6 +183,8 @@ struct sigp_handle {
   int opt_strip_min = 512;
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
+  int opt_kbuild_mfma = 2;   // covariance build: squared distances in GEMM form on the matrix pipe (kbuild_mfma_kernel): 2 = from 16 features on (below, the 2 d
+                             // VALU instructions per element are not what the build waits for: same time either way), 1 = always, 0 = never (VALU)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
   int opt_schedule = 0;      // 0 right-looking outer panels (K = 128*outer per trailing update), 1 left-looking (K grows to n)
   int opt_trsm128 = 256;     // panel solve on 128-row tiles (LDS-DMA kernel) once rows_below*members reaches this
@@ -535,6 +537,20 @@ int upload_kparams(sigp_handle* h, Slot& s, int nb, hipStream_t st = nullptr) {
   return SIGP_OK;
 }
 
+// covariance build of a tile set: squared distances in GEMM form on the matrix pipe (kbuild_mfma_kernel, option kbuild_mfma, default) or
+// feature by feature on the VALU (kbuild_kernel)
+template <typename TO>
+void launch_kbuild(sigp_handle* h, dim3 grid, hipStream_t st, const double* X, long strideX, int dp, int d, int n, TO* Mat, long strideM, long ld,
+                   const KParams* kps, int flags, int colblk0 = 0, double* Mat64 = nullptr, long stride64 = 0) {
+  if (h->opt_kbuild_mfma == 1 || (h->opt_kbuild_mfma == 2 && d >= 16)) {
+    if (d <= 8) hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 8>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
+    else hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 32>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
+    return;
+  }
+  if (d <= 8 && std::is_same<TO, double>::value) hipLaunchKernelGGL((kbuild_kernel<TO, 8>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
+  else hipLaunchKernelGGL(kbuild_kernel<TO>, grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
+}
+
 // RBF / Matern build of K~ (lower) + ride rows for the nb lockstep members of slot s.  Member b uses data set
 // kps[b].ds: X + ds*strideX, y + ds*stridey, Xs + ds*strideXs.
 int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, const double* y, long stridey, const double* Xs,
@@ -543,8 +559,7 @@ int build_cov(sigp_handle* h, Slot& s, int nb, const double* X, long strideX, co
   hipStream_t st = stb ? stb : s.s_upd;
   ProfScope ps(h, st, SIGP_KC_KBUILD, nb * ((double)n * n / 2 * (3.0 * d + 20)), nb * (8.0 * n * d + 4.0 * n * (n + 1)));
   dim3 grid((unsigned)kbuild_tiles(n_pad), 1, (unsigned)nb);
-  if (d <= 8) hipLaunchKernelGGL((kbuild_kernel<double, 8>), grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
-  else hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
+  launch_kbuild<double>(h, grid, st, X, strideX, (int)dp, (int)d, (int)n, s.mat, s.matStride, ld, s.kps, 0);
   HIPCHK(h, hipGetLastError());
   dim3 g2((unsigned)((n_pad + 255) / 256), RIDE, (unsigned)nb);
   hipLaunchKernelGGL(ride_build_kernel<double>, g2, dim3(256), 0, st, X, strideX, Xs, strideXs, y, stridey, (int)dp, (int)d, (int)n,
@@ -1249,6 +1264,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_tol_e")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_refine_tol_e = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
   if (!strcmp(name, "update_dbg")) { h->opt_update_dbg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "c_dma")) {
@@ -1990,7 +2006,7 @@ int sigp_nlml_grad(sigp_handle* h, int kernel_id, const double theta[2], const d
     s.kps_host[0] = make_kparams(kernel_id == SIGP_KERNEL_RBF ? KID_RBF_DLOGL : KID_MATERN52_DLOGL, ell, 0.0, 0);
     if ((rc = upload_kparams(h, s, 1))) return rc;
     dim3 grid((unsigned)(n_pad / KB_TN), (unsigned)(n_pad / KB_TM), 1);
-    hipLaunchKernelGGL(kbuild_kernel<double>, grid, dim3(256), 0, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
+    launch_kbuild<double>(h, grid, st, h->X, 0L, (int)h->dp, (int)h->d, (int)n, h->gD, 0L, ld, s.kps, 1);
     HIPCHK(h, hipGetLastError());
   }
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)n), dim3(256), 0, st, h->gK, h->gD, h->scratchZ, ld, (int)n, h->gPart);
