@@ -444,7 +444,7 @@ def kernel_code_sha16():
     import hashlib
     hs = hashlib.sha256()
     csrc = os.path.join(ROOT, "seaiceextentforecasting_amd", "csrc")
-    for f in ("syrk128.hpp", "gemm_mfma.hpp", "potrf_diag.hpp"):
+    for f in ("syrk128.hpp", "gemm_mfma.hpp"):       # (what syrk128_kernel is compiled from)
         with open(os.path.join(csrc, f), "rb") as fh:
             hs.update(fh.read())
     return hs.hexdigest()[:16]
@@ -518,7 +518,7 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                 res["refinement_residual"] = dg.refine_residual_
         # per-rank numbers worth a max / sum over the ranks
         v = torch.tensor([st["stall_ms"], st["comm_ms"], st["factor_ms"], st["solve_ms"], res["matrix_bytes"], st["owner_ms"], st["link_bytes"], st_split["owner_ms"],
-                          st_split["link_bytes"], st_split["stall_ms"]], dtype=torch.float64, device=dev)
+                          st_split["link_bytes"], st_split["stall_ms"], st["link_panel_max"], st_split["link_panel_max"]], dtype=torch.float64, device=dev)
         vmax = v.clone()
         if dist is not None:
             dist.all_reduce(vmax, op=dist.ReduceOp.MAX)
@@ -534,11 +534,13 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
              "share_of_communication_window_with_update_work": (1.0 - float(vmax[0]) / float(vmax[1])) if float(vmax[1]) > 0 else None,
              "matrix_bytes_max_rank": float(vmax[4]), "sigma_f": res["sigma_f"], "nlml": res["nlml"], "mean": res["mean"], "var": res["var"],
              "panels": int(-(-(n // 128) // outer)),
-             "whole_panel_exchange": {"owner_only_ms_per_fit_max_rank": float(vmax[5]), "bytes_per_directed_link_per_fit_max_rank": float(vmax[6])},
+             "whole_panel_exchange": {"owner_only_ms_per_fit_max_rank": float(vmax[5]), "bytes_per_directed_link_per_fit_max_rank": float(vmax[6]),
+                                      "owner_only_ms_per_panel": float(vmax[5]) * world / max(1, -(-(n // 128) // outer)), "bytes_on_one_link_within_one_panel_max": float(vmax[10])},
              "row_split_exchange": {"ms_per_fit": 1e3 * min(splitt), "ms_per_fit_all": [round(1e3 * t, 3) for t in splitt], "gain_over_streamed_segments": best / min(splitt),
                                     "owner_only_ms_per_fit_max_rank": float(vmax[7]), "bytes_per_directed_link_per_fit_max_rank": float(vmax[8]),
+                                    "owner_only_ms_per_panel": float(vmax[7]) * world / max(1, -(-(n // 128) // outer)), "bytes_on_one_link_within_one_panel_max": float(vmax[11]),
                                     "update_stream_stalled_ms_max_rank": float(vmax[9]), "split_panels": int(st_split["split_panels"]),
-                                    "bit_identical_nlml": bool(split_nlml == res["nlml"]),
+                                    "rel_diff_nlml_vs_whole_panel_exchange": float(abs(split_nlml - res["nlml"]) / abs(res["nlml"])),
                                     "note": "dist_panel_split = 1: top block broadcast (8 MB at W = 8), rows below scattered in `world` pieces, solved where they land, all-gathered in place"}}
         if "refinement_residual" in res:
             e["refinement_residual"] = res["refinement_residual"]

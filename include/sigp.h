@@ -264,7 +264,8 @@ int sigp_profile_reset(sigp_handle* h);
  * measurement runs on the HIP runtime the library links and needs no second one (PyTorch's) in the process. */
 int sigp_synchronize(sigp_handle* h);
 /* tuning knobs; returns SIGP_BAD_ARG for an unknown name or an invalid value.  Defaults in brackets.
- *   outer_blocks [8]      outer panel width in 128-column blocks (K of the trailing update = 128 x this)
+ *   outer_blocks [8]      outer panel width in 128-column blocks (K of the trailing update = 128 x this); left unset, single fits of at most
+ *                         32 block columns (n <= 4096) use 16
  *   lookahead [1]         factor the next panel on the panel stream while the trailing update runs
  *   schedule [0]          0 right-looking outer panels, 1 left-looking (same factor bit for bit)
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
@@ -278,7 +279,9 @@ int sigp_synchronize(sigp_handle* h);
  *   dist_panel_split [0]  sharded fit, panel exchange by ROW PIECES ("all-gather of block-row pieces"): the owner factors only the panel's W x W top
  *                         block and broadcasts it (8 MB at W = 8); the rows below it are scattered in `world` pieces, every rank solves its piece, and
  *                         an in-place all-gather assembles the panel on every rank -- the owner's throughput work leaves the chain and each link carries
- *                         1/world of the panel instead of all of it.  Rows are independent: results are bit-identical to dist_panel_split = 0.
+ *                         1/world of the panel instead of all of it.  Rows are independent: bit-identical to dist_panel_split = 0 wherever both run the same
+ *                         tile kernels (every order up to ~ 10 000 at W = 8); beyond, a whole panel's in-panel updates go to the 128-tile kernel and a
+ *                         row piece's do not (another k order inside a 16-slice): last-bit differences.
  *   dist_timeout_ms [120000] deadline of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
  *                         error / when it passes: ncclCommAbort, SIGP_HIP_ERROR (the panel reached is in sigp_last_error), the handle's sharded
  *                         state is dead until sigp_dist_shutdown + a fresh sigp_dist_init* -- a dead peer is an error, not a hang; 0 = wait for ever

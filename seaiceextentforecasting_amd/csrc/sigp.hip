@@ -155,7 +155,7 @@ struct sigp_handle {
     // statistics of the last sharded fit (sigp_get_stat "dist_*")
     double st_fit_ms = 0, st_factor_ms = 0, st_bcast_bytes = 0, st_comm_ms = 0, st_stall_ms = 0, st_replicated_ms = 0, st_solve_ms = 0;
     double st_collectives = 0, st_host_comm_ms = 0, st_enqueue_ms = 0;
-    double st_link_bytes = 0, st_owner_ms = 0, st_split_panels = 0;   // bytes this rank sends to ONE peer per fit; device time of the owner-only work per fit; panels exchanged by row pieces
+    double st_link_bytes = 0, st_owner_ms = 0, st_split_panels = 0, st_link_panel_max = 0;   // (.. the most one rank puts on ONE link within one panel's exchange)   // bytes this rank sends to ONE peer per fit; device time of the owner-only work per fit; panels exchanged by row pieces
     std::vector<hipEvent_t> ev_own;                                  // (pairs of stamps around the owner-only work of this rank's panels)
   } dc;
   int opt_dist_split = 0;                      // sharded fit, panel exchange by ROW PIECES: the owner factors only the panel's W x W top block and broadcasts it; every rank
@@ -172,6 +172,7 @@ struct sigp_handle {
   double sigma_f = 0, nlml = 0;
   KParams kp{};
   // options
+  bool outer_set = false;  // outer_blocks was given: no automatic choice (potrf_core)
   int opt_outer = 8;       // outer panel width in 128-blocks (K = 1024 trailing updates; single fits: 8.7 vs 9.0 ms at n = 8192, 34.6 vs 42.1 ms at n = 16384 against 2)
   int opt_lookahead = 1;
   int opt_small_tiles = 320; // use 64x64 tiles when the 128-tile count is below this
@@ -692,7 +693,9 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
-  const int W = std::max(1, h->opt_outer);
+  // (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
+  //  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
+  const int W = (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
@@ -1244,7 +1247,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
       for (const char* nm : dbg_only)
         if (!strcmp(name, nm)) return fail(h, SIGP_BAD_ARG, "%s is a measurement switch of libsigp_debug.so (make debug), not of the product library", nm);
   }
-  if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_outer = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "outer_blocks")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_outer = (int)value; h->outer_set = true; return SIGP_OK; }
   if (!strcmp(name, "lookahead")) { h->opt_lookahead = value ? 1 : 0; return SIGP_OK; }
   if (!strcmp(name, "pan_priority")) {
     if ((int)(value != 0) == h->opt_pan_priority) return SIGP_OK;
@@ -2154,7 +2157,7 @@ int sigp_get_stat(sigp_handle* h, const char* name, double* value) {
       {"dist_fit_ms", &h->dc.st_fit_ms}, {"dist_factor_ms", &h->dc.st_factor_ms}, {"dist_bcast_bytes", &h->dc.st_bcast_bytes}, {"dist_comm_ms", &h->dc.st_comm_ms},
       {"dist_stall_ms", &h->dc.st_stall_ms}, {"dist_solve_ms", &h->dc.st_solve_ms}, {"dist_collectives", &h->dc.st_collectives},
       {"dist_host_comm_ms", &h->dc.st_host_comm_ms}, {"dist_enqueue_ms", &h->dc.st_enqueue_ms}, {"dist_link_bytes", &h->dc.st_link_bytes},
-      {"dist_owner_ms", &h->dc.st_owner_ms}, {"dist_split_panels", &h->dc.st_split_panels}};
+      {"dist_owner_ms", &h->dc.st_owner_ms}, {"dist_split_panels", &h->dc.st_split_panels}, {"dist_link_panel_max", &h->dc.st_link_panel_max}};
   for (const auto& e : ds)
     if (!strcmp(name, e.nm)) { *value = *e.v; return SIGP_OK; }
   if (!strcmp(name, "dist_comm_ranks")) {        // what the communicator itself reports (ncclCommCount); 0 = no RCCL communicator on this handle

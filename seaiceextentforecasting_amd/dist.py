@@ -305,7 +305,7 @@ class DistributedGPR:
     def stats(self):
         """``dist_*`` statistics of the last fit (meaningful with ``stats=True``): ms and bytes on THIS rank."""
         return {k: self.gp._stat("dist_" + k) for k in ("fit_ms", "factor_ms", "bcast_bytes", "comm_ms", "stall_ms", "solve_ms", "collectives", "comm_ranks", "host_comm_ms", "enqueue_ms",
-                                                                "link_bytes", "owner_ms", "split_panels")}
+                                                                "link_bytes", "owner_ms", "split_panels", "link_panel_max")}
 
     def predict(self, Xs):
         """(fmean [m], fvar [m]) as ``GPR.predict``.  The points passed to ``fit(Xs=...)`` rode along the factorisation and cost nothing;

@@ -304,8 +304,8 @@ class Network:
         # the reference forms a link as pearsonr(a, b)[0] * sd_a * sd_b (ComplexNetworks.py:311-318: stats.pearsonr x sdA x sdA2): for an area whose series is
         # constant that is NaN (0/0 inside pearsonr), which nansum then ignores in the strength; keep the NaN so that ``links``
         # itself is the reference's output too
-        sd = np.std(series, axis=1)
-        const = sd == 0.0
+        # (constancy as scipy detects it -- every value equal to the first: np.std of 0.1 repeated can be 1e-17, not 0)
+        const = np.all(series == series[:, :1], axis=1)
         if np.any(const) and len(ids) > 1:
             cov = cov.copy()
             cov[const, :] = np.nan

@@ -293,12 +293,18 @@ with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=8, stats=
     print("rank", rank, dg.stats(), flush=True)
     keep = (mu.copy(), var.copy(), dg.nlml_, dg.stats())
 with S.DistributedGPR("rbf", rank, world, dist, device=0, outer_blocks=8, stats=True, panel_split=True) as dg:
-    dg.fit(X, y, float(z["ell"]), float(z["sn"]), Xs=Xs)     # the same fit with the panels exchanged by row pieces + all-gather: the same bits
+    dg.fit(X, y, float(z["ell"]), float(z["sn"]), Xs=Xs)     # the same fit with the panels exchanged by row pieces + all-gather
     mu, var = dg.predict(Xs)
-    assert np.array_equal(mu, keep[0]) and np.array_equal(var, keep[1]) and dg.nlml_ == keep[2], (rank, "row-split panel exchange changed the bits")
+    assert rel(mu, z["fmean"]) <= 1e-8 and rel(var, z["fvar"]) <= 1e-8 and rel(dg.nlml_, z["nlml"]) <= 1e-9 and rel(dg.sigma_f_, z["sigma_f"]) <= 1e-9      # == oracle
+    # At this order the two exchanges do not run the same tile kernels: a whole panel's in-panel K = 256 / 512 updates have >= 320 128-tiles
+    # and go to syrk128_kernel (whose k order inside a 16-slice is 0,2,4,6 | 1,3,5,7), a rank's row piece of them stays on the 64 x 64-tile
+    # kernel (0..3 | 4..7): last-bit differences, not the bit identity asserted at the test sizes where both paths pick the same kernels
+    assert rel(mu, keep[0]) <= 1e-11 and rel(var, keep[1]) <= 1e-11 and rel(dg.nlml_, keep[2]) <= 1e-13, (rank, rel(mu, keep[0]), rel(dg.nlml_, keep[2]))
     st = dg.stats()
     assert st["split_panels"] >= 10, st
-    assert st["link_bytes"] < 0.75 * keep[3]["link_bytes"] or rank != 0, (st["link_bytes"], keep[3]["link_bytes"])     # an owner's links carry pieces, not whole panels
+    # what an owner puts on ONE link within one panel's exchange: two half-panels + the top block here (world = 2; 2/world of a panel in general),
+    # a whole panel with the broadcast; and the owner-only device time per fit shrinks to the top blocks' chains
+    assert st["link_panel_max"] <= 1.2 * keep[3]["link_panel_max"] and st["owner_ms"] < keep[3]["owner_ms"], (st, keep[3])
     print("rank", rank, "row-split", st, flush=True)
 dist.barrier(); dist.destroy_process_group()
 open(os.path.join(%(out)r, "ok_%%d" %% rank), "w").write("ok")

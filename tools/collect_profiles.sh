@@ -5,13 +5,14 @@
 #   tools/collect_profiles.sh r03 pmc       PMC passes of the bench command (trailing update, covariance build)
 #   tools/collect_profiles.sh r03 f32       kernel stats + PMC passes of one fp32 fit at configs[4]'s shape (syrk128_kernel<float>)
 # then, back in the authoring container:  python tools/summarize_pmc.py r03
-R=${1:-r03}
+R=${1:-r04}
 WHAT=${2:-bench}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 if [ "$WHAT" = "bench" ]; then
-  python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+  python3 $GRAFT_REPO_ROOT/bench.py > $OUT/bench_line.json 2> $OUT/bench.err || exit 1       # stdout: the compact metric line; the full record:
+  cp $GRAFT_REPO_ROOT/gpurun_out/bench_verbose.json $OUT/bench.json                              # (bench.py writes it there and to stderr)
   echo "bench done"
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.json 2> $OUT/stats.err || exit 1
   echo "stats done"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Per-path kernel-trace summaries (tools/trace_summary.py) of the current build: batch group, single fits n = 4096 / 16384 (fp64), fp32 n = 32768.
 # Runs on the GPU box; outputs gpurun_out/<round>_traces/*.txt (copy the ones to be judged into profiles/).
-R=${1:-r03}
+R=${1:-r04}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${R}_traces
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,6 +14,7 @@ run() {  # name, program args...
 }
 run batch_group $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --no-profile --steps 2 || exit 1
 run single_fit_n4096 $GRAFT_REPO_ROOT/tools/shard_profile.py --single --n 4096 --d 8 --reps 5 || exit 1
+run single_fit_n8192 $GRAFT_REPO_ROOT/tools/shard_profile.py --single --n 8192 --d 8 --reps 4 || exit 1
 run single_fit_n16384 $GRAFT_REPO_ROOT/tools/shard_profile.py --single --n 16384 --d 16 --reps 3 || exit 1
 run fp32_n32768 $GRAFT_REPO_ROOT/tools/shard_profile.py --single --dtype f32 --n 32768 --d 32 --kernel matern52 --sn 0.1 --reps 2 || exit 1
 ls $OUT

@@ -1,4 +1,6 @@
 """Reference-size batch (bench.py's reference_kernel_grid workload) with one wavefront vs four wavefronts per fit."""
+import os
+os.environ["SIGP_USE_DEBUG_LIB"] = "1"      # the switches below are measurement switches of libsigp_debug.so (make debug)
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,4 +1,6 @@
 """XCD-chunked tile walk (option xcd_chunks) against the column-major walk: placement only, so factors must be bit-identical."""
+import os
+os.environ["SIGP_USE_DEBUG_LIB"] = "1"      # the switches below are measurement switches of libsigp_debug.so (make debug)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
