@@ -310,7 +310,7 @@ def main():
             # command (FETCH_SIZE / WRITE_SIZE cannot share a pass, and PMC collection serialises kernels), summarised under
             # profiles/ by tools/collect_profiles.sh + tools/summarize_pmc.py
             # ... and quoted only when the file was collected from THIS kernel code (sha of the csrc files recorded at collection time)
-            for rnd in ("r03", "r02"):
+            for rnd in ("r04", "r03", "r02"):
                 pth = os.path.join(ROOT, "profiles", "%s_pmc_syrk128.json" % rnd)
                 if not os.path.exists(pth):
                     continue

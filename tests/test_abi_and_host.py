@@ -454,12 +454,38 @@ def test_plain_c_program_runs_the_hot_path_and_the_sharded_fit(tmp_path):
 
 
 def test_committed_pmc_summary_belongs_to_the_committed_kernel_code():
-    """bench.py quotes roofline.traffic from profiles/r03_pmc_syrk128.json only while the sha of the kernel sources recorded in it equals the
+    """bench.py quotes roofline.traffic from profiles/r04_pmc_syrk128.json only while the sha of the kernel sources recorded in it equals the
     tree's (a stale file is refused, and the line then carries traffic = null).  The file committed with the tree must be the tree's."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    pm = json.load(open(os.path.join(root, "profiles", "r03_pmc_syrk128.json")))
+    pm = json.load(open(os.path.join(root, "profiles", "r04_pmc_syrk128.json")))
     assert pm["kernel_code_sha16"] == bench.kernel_code_sha16()
     assert pm["traffic_bytes_per_launch"] > 0 and 0.5 < pm["mfma_pipe_busy_fraction"] <= 1.0
+    for other in ("r04_pmc_kbuild.json", "r04_pmc_syrk128_f32.json"):        # the round's other PMC summaries exist and carry what DESIGN.md quotes from them
+        d = json.load(open(os.path.join(root, "profiles", other)))
+        assert d.get("hbm_total_GBps", d.get("tflops_in_kernel", 0)) > 0, other
+
+
+def test_bench_compact_line_fits_the_drivers_tail():
+    """bench.py prints ONE line on stdout: the compact metric line (the driver keeps a 2 000-character tail).  Built from the committed full record
+    it must stay below 1.5 KB and carry the contract's fields, `roofline`, `cpu_baseline`, the parity of the timed step and the other configs."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    full = json.load(open(os.path.join(root, "profiles", "r04_bench_line_verbose.json")))
+    c = bench.compact_line(full)
+    txt = json.dumps(c)
+    assert len(txt) <= 1536, len(txt)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert c["vs_baseline"] is None and c["dtype"] == "f64" and "workload" in c["config"] and "model" not in c["config"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    for k in ("c1_ms", "c3_ms", "c4_ms", "c4_frac", "mlii_g40_ms"):
+        assert k in c and c[k] > 0, k
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-3

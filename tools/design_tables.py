@@ -1,0 +1,100 @@
+"""Regenerate the measured tables of DESIGN.md (between the GENERATED markers) from profiles/<round>_*: every figure names the file it comes from.
+    python tools/design_tables.py [r04]        (rewrites DESIGN.md in place; prints the tables)"""
+import csv, json, os, re, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
+v = json.load(open(P("bench_line_verbose.json")))
+pm = json.load(open(P("pmc_syrk128.json")))
+kb = json.load(open(P("pmc_kbuild.json")))
+f32 = json.load(open(P("pmc_syrk128_f32.json")))
+stats = {r["Name"]: r for r in csv.DictReader(open(P("rocprofv3_kernel_stats.csv")))}
+def stat(prefix):
+    for k, r in stats.items():
+        if prefix in k:
+            return int(r["Calls"]), float(r["AverageNs"]) / 1e6
+    return 0, float("nan")
+rf = v["roofline"]
+oc = v["other_configs"]
+def trace(name):
+    """first line + per-kernel table of a trace summary"""
+    try:
+        return open(P("trace_%s.txt" % name)).read().splitlines()
+    except OSError:
+        return []
+def trace_kernel(name, kern):
+    for ln in trace(name):
+        if ln.startswith(kern):
+            f = ln.split()
+            return int(f[-3]), float(f[-2]), float(f[-1])
+    return None
+
+out = []
+A = out.append
+A("<!-- BEGIN GENERATED: tables (tools/design_tables.py %s) -->" % R)
+A("")
+A("**Headline** (`profiles/%s_bench_line_verbose.json`, the default `python bench.py`, CPU protocol included; compact form `profiles/%s_bench_line.json`):" % (R, R))
+A("")
+A("| quantity | value | source |")
+A("|---|---|---|")
+A("| GP fits/s, configs[2] (n = %d, d = %d, 40 years in lockstep per step) | **%.1f** (%.2f ms per 40-fit step; %.1f without the event brackets) | `value`, `ms_per_step`, `without_event_brackets` |"
+  % (v["config"]["n"], v["config"]["d"], v["value"], v["ms_per_step"], v.get("without_event_brackets", {}).get("value", float("nan"))))
+A("| whole fit, fraction of the fp64 MFMA peak (78.6 TFLOP/s) | %.3f (%.1f TFLOP/s) | `whole_fit_frac_of_fp64_mfma_peak` |" % (v["whole_fit_frac_of_fp64_mfma_peak"], v["whole_fit_tflops"]))
+A("| `roofline`: `syrk128_kernel<double>` by HIP events over the timed region | **%.3f** = %.2f TFLOP/s; %d launches, avg %.3f ms, %.4g flop each | `roofline` |"
+  % (rf["frac"], rf["achieved"], rf["launches"], rf["avg_launch_ms"], rf["flops_per_launch"]))
+c, a = stat("syrk128_kernel<double, false, false")
+A("| the same kernel in `rocprofv3 --kernel-trace --stats` of the same command | %d calls, avg %.3f ms (%.1f %% from the HIP-event average) | `profiles/%s_rocprofv3_kernel_stats.csv` |" % (c, a, 100 * abs(a - rf["avg_launch_ms"]) / rf["avg_launch_ms"], R))
+A("| ... when the strip solve does not share the chip with it (`roofline.unshared`) | %.3f (%.1f TFLOP/s) | `roofline.unshared` |" % (rf["unshared"]["frac"], rf["unshared"]["achieved"]))
+A("| HBM-side traffic of that kernel per launch (PMC, separate passes) | %.2f GB fetched (FETCH_SIZE x 2) + %.2f GB written = **%.2f GB**; algorithmic C bytes %.2f GB; matrix pipe busy %.3f | `profiles/%s_pmc_syrk128.json` |"
+  % (pm["fetch_bytes_per_launch_corrected"] / 1e9, pm["write_bytes_per_launch"] / 1e9, pm["traffic_bytes_per_launch"] / 1e9, rf.get("algorithmic_c_bytes_per_launch", 0) / 1e9, pm["mfma_pipe_busy_fraction"], R))
+cb = v["cpu_baseline"]
+A("| CPU baseline (oracle in the reference's call sequence, %d BLAS threads, 1 warm-up + 3 timed, median) | %.4f fits/s (%.1f s per fit); best practice %.1f s; GPU / CPU = %.0f (context, not credit) | `cpu_baseline`, `cpu_baseline_best_practice` |"
+  % (cb["cores"], cb["value"], cb["seconds"], v["cpu_baseline_best_practice"]["seconds"], v["vs_cpu_baseline"]))
+pr = v["parity"]
+A("| parity of the first timed step vs the oracle (mean / variance / nlML, relative) | %.1e / %.1e / %.1e (tolerance 1e-8) | `parity` |" % (pr["batch_step0_mean_rel"], pr["batch_step0_var_rel"], pr["batch_step0_nlml_rel"]))
+A("| covariance build `kbuild_kernel<double,8>`, 40 members per launch | %.3f ms; %.2f GB written + %.2f GB fetched (PMC) = %.2f TB/s = %.2f of 8 TB/s; algorithmic %.2f GB -> %.2f TB/s | `profiles/%s_pmc_kbuild.json` |"
+  % (kb["rocprofv3_stats_avg_ms"], kb["write_bytes_per_launch"] / 1e9, kb["fetch_bytes_per_launch_corrected"] / 1e9, kb["hbm_total_GBps"] / 1e3, kb["frac_of_8TBps"], kb["algorithmic_bytes_per_launch"] / 1e9,
+     kb["algorithmic_bytes_per_launch"] / (kb["rocprofv3_stats_avg_ms"] * 1e-3) / 1e12, R))
+A("| `syrk128_kernel<float>` over all launches of a configs[4] fit | %.1f TFLOP/s = %.3f of 157.3; matrix pipe busy %s | `profiles/%s_pmc_syrk128_f32.json` |"
+  % (f32["tflops_in_kernel"], f32["frac_of_fp32_mfma_peak"], ("%.3f" % f32["mfma_pipe_busy_fraction"]) if "mfma_pipe_busy_fraction" in f32 else "n/a", R))
+A("")
+A("**Other BASELINE configurations on one GPU** (untimed extras of the same run, `other_configs` of `profiles/%s_bench_line_verbose.json`; kernel-trace summaries `profiles/%s_trace_*.txt`):" % (R, R))
+A("")
+A("| configuration | measured | where the time goes (trace) |")
+A("|---|---|---|")
+def oc_get(prefix):
+    for k, x in oc.items():
+        if k.startswith(prefix):
+            return x
+    return {}
+c1, c3, c4, c4g = oc_get("configs[1]"), oc_get("configs[3]"), oc_get("configs[4] n="), oc_get("configs[4] shape")
+def tk(name, kern, label):
+    t = trace_kernel(name, kern)
+    return "%s %d x %.1f us" % (label, t[0], t[2]) if t else ""
+A("| configs[1] n = 4096, d = 8 fp64 RBF, single fit | **%.3f ms** (%.1f fits/s, %.3f of peak) | %s; %s; %s; %s (`%s_trace_single_fit_n4096.txt`, outer width 8) |"
+  % (c1.get("ms_per_fit", 0), c1.get("fits_per_s", 0), c1.get("frac_of_peak", 0), tk("single_fit_n4096", "diag_update_kernel<double>", "diagonal block + ride"), tk("single_fit_n4096", "chain_link_kernel<double>", "link"),
+     tk("single_fit_n4096", "potrf_diag_kernel<double>", "first block of a panel"), tk("single_fit_n4096", "gemm_mfma_kernel<double, 64, 64", "panel-boundary updates"), R))
+A("| n = 8192, d = 8, single fit | %s | %s; %s; %s |" % ((trace("single_fit_n8192") or ["?"])[0], tk("single_fit_n8192", "diag_update_kernel<double>", "diagonal block + ride"), tk("single_fit_n8192", "chain_link_kernel<double>", "link"),
+                                                  tk("single_fit_n8192", "syrk128_kernel<double, false", "trailing updates")))
+A("| configs[3] n = 16384, d = 16 fp64 RBF, single fit on one GPU | **%.2f ms** (%.3f of peak) | %s; %s; %s; %s |"
+  % (c3.get("ms_per_fit", 0), c3.get("frac_of_peak", 0), tk("single_fit_n16384", "syrk128_kernel<double, false", "trailing updates"), tk("single_fit_n16384", "diag_update_kernel<double>", "diagonal block + ride"),
+     tk("single_fit_n16384", "chain_link_kernel<double>", "link"), tk("single_fit_n16384", "potrf_diag_kernel<double>", "plain diagonal blocks")))
+A("| configs[4] n = 32768, d = 32 fp32 Matern-5/2 + fp64 refinement, single fit | **%.1f ms** (%.3f of the fp32 peak; refinement residual %.1e); lockstep group of 4: %.1f ms per fit (%.3f) | %s; %s; %s |"
+  % (c4.get("ms_per_fit", 0), c4.get("frac_of_peak", 0), c4.get("refinement_residual", 0), c4g.get("ms_per_fit", 0), c4g.get("frac_of_peak", 0), tk("fp32_n32768", "syrk128_kernel<float, false", "trailing updates"),
+     tk("fp32_n32768", "kres_lower_rows_kernel", "residual row pass"), tk("fp32_n32768", "kbuild_mfma_kernel<float, 32>", "covariance build")))
+ml = oc.get("mlii", {})
+A("| MLII (nlML + exact gradient) | single fit: %.2f ms at n = 4096, %.2f ms at n = 8192 (%.2f of peak); lockstep group of 40: %.2f ms per evaluation at n = 4096 (%.2f), **%.2f ms at n = 8192 (%.2f)** | |"
+  % (ml.get("n=4096", {}).get("ms", 0), ml.get("n=8192", {}).get("ms", 0), ml.get("n=8192", {}).get("frac_of_fp64_mfma_peak", 0), ml.get("n=4096 lockstep group of 40", {}).get("ms_per_evaluation", 0),
+     ml.get("n=4096 lockstep group of 40", {}).get("frac_of_fp64_mfma_peak", 0), ml.get("n=8192 lockstep group of 40", {}).get("ms_per_evaluation", 0), ml.get("n=8192 lockstep group of 40", {}).get("frac_of_fp64_mfma_peak", 0)))
+rk = oc.get("reference_kernel_grid", {})
+A("| reference kernel at reference size: 3 regions x 40 years x 20 x 20 grid = %d fits, one launch | %.2f ms per call (%.1f M fits/s incl. copies) vs %.1f k fits/s for the oracle's loop on the host | |"
+  % (rk.get("fits", 0), rk.get("ms_per_launch", 0), rk.get("fits_per_s", 0) / 1e6, rk.get("cpu_oracle_loop", {}).get("fits_per_s", 0) / 1e3))
+A("")
+A("<!-- END GENERATED -->")
+txt = "\n".join(out)
+print(txt)
+dp = os.path.join(ROOT, "DESIGN.md")
+d = open(dp).read()
+if "<!-- BEGIN GENERATED" in d:
+    d = re.sub(r"<!-- BEGIN GENERATED.*?<!-- END GENERATED -->", lambda m: txt, d, flags=re.S)
+    open(dp, "w").write(d)
