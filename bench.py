@@ -419,7 +419,8 @@ def compact_line(out):
         if k.startswith("n=8192 lockstep") and isinstance(v, dict):
             c["mlii_g40_ms"] = round(v["ms_per_evaluation"], 3); c["mlii_g40_frac"] = round(v["frac_of_fp64_mfma_peak"], 4)
     if "sharded" in out and isinstance(out["sharded"], dict):
-        c["sharded"] = {k: ({"ms_per_fit": round(v.get("ms_per_fit", 0.0), 3), "speedup_vs_1gpu": round(v.get("single_gpu", {}).get("speedup_of_sharded", 0.0), 3),
+        c["sharded"] = {k: ({"ms_per_fit": round(v.get("ms_per_fit", 0.0), 3), "row_split_ms_per_fit": round(v.get("row_split_exchange", {}).get("ms_per_fit", 0.0), 3),
+                             "speedup_vs_1gpu": round(v.get("single_gpu", {}).get("speedup_of_sharded", 0.0), 3),
                              "transport": str(v.get("transport"))[:40]} if isinstance(v, dict) and "ms_per_fit" in v else str(v)[:80]) for k, v in out["sharded"].items()}
     c["verbose"] = "stderr; gpurun_out/bench_verbose.json"
     return c
@@ -493,29 +494,34 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                     dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 whole.append(float(t.item()))
             dg.gp.set_option("dist_segment", 2)
-            # ... and for the panel exchange by ROW PIECES + all-gather (dist_panel_split: the owner factors only the top block, every rank solves
-            # 1/world of the rows below it): the same bits, another critical path
-            dg.gp.set_option("dist_panel_split", 1)
-            dg.refit(ell, sn)
-            splitt = []
-            for r_ in range(reps):
-                torch.cuda.synchronize()
-                if dist is not None:
-                    dist.barrier()
-                t0 = time.perf_counter()
-                dg.refit(ell, sn)
-                t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-                if dist is not None:
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                splitt.append(float(t.item()))
-            st_split = dg.stats()
-            split_nlml = dg.nlml_
-            dg.gp.set_option("dist_panel_split", 0)
             dg.refit(ell, sn)
             mu, var = dg.predict(Xs)
-            res = dict(sigma_f=dg.sigma_f_, nlml=dg.nlml_, mean=float(mu[0]), var=float(var[0]), matrix_bytes=dg.matrix_bytes_, transport=dg.transport)
+            keep = dict(sigma_f=dg.sigma_f_, nlml=dg.nlml_, mean=float(mu[0]), var=float(var[0]), matrix_bytes=dg.matrix_bytes_, transport=dg.transport)
             if dtype == "f32":
-                res["refinement_residual"] = dg.refine_residual_
+                keep["refinement_residual"] = dg.refine_residual_
+            # ... and for the panel exchange by ROW PIECES + all-gather (dist_panel_split: the owner factors only the top block, every rank solves
+            # 1/world of the rows below it): the same results, another critical path.  LAST, and in a try of its own: whatever happens to it
+            # (a collective that times out marks the handle dead) must not cost the record the numbers above
+            splitt, st_split, split_nlml, split_err = [], dict(st), float("nan"), None
+            try:
+                dg.gp.set_option("dist_panel_split", 1)
+                dg.refit(ell, sn)
+                for r_ in range(reps):
+                    torch.cuda.synchronize()
+                    if dist is not None:
+                        dist.barrier()
+                    t0 = time.perf_counter()
+                    dg.refit(ell, sn)
+                    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+                    if dist is not None:
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    splitt.append(float(t.item()))
+                st_split = dg.stats()
+                split_nlml = dg.nlml_
+            except Exception as e:               # noqa: BLE001
+                split_err = "%s: %s" % (type(e).__name__, str(e)[:300])
+                splitt = splitt or [float("nan")]
+            res = keep
         # per-rank numbers worth a max / sum over the ranks
         v = torch.tensor([st["stall_ms"], st["comm_ms"], st["factor_ms"], st["solve_ms"], res["matrix_bytes"], st["owner_ms"], st["link_bytes"], st_split["owner_ms"],
                           st_split["link_bytes"], st_split["stall_ms"], st["link_panel_max"], st_split["link_panel_max"]], dtype=torch.float64, device=dev)
@@ -541,6 +547,7 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                                     "owner_only_ms_per_panel": float(vmax[7]) * world / max(1, -(-(n // 128) // outer)), "bytes_on_one_link_within_one_panel_max": float(vmax[11]),
                                     "update_stream_stalled_ms_max_rank": float(vmax[9]), "split_panels": int(st_split["split_panels"]),
                                     "rel_diff_nlml_vs_whole_panel_exchange": float(abs(split_nlml - res["nlml"]) / abs(res["nlml"])),
+                                    "error": split_err,
                                     "note": "dist_panel_split = 1: top block broadcast (8 MB at W = 8), rows below scattered in `world` pieces, solved where they land, all-gathered in place"}}
         if "refinement_residual" in res:
             e["refinement_residual"] = res["refinement_residual"]

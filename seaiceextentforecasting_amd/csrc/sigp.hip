@@ -203,6 +203,7 @@ struct sigp_handle {
                                      // ONE launch that does only what the next diagonal block needs (chain_link_kernel), the rest rides;
                                      // bit 3: the binary recursion's leaf pairs (two columns) take that form too
   int opt_chain_rows = 80;           // (see panel_any)
+  int opt_link_rows = 256;           // fused chain link while rows-below x members stays under this (chain_panel)
   int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_head_gate = 16;    // pipeline_head = 3: a group's tail begins when at most this many block columns remain behind the panel just enqueued
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
@@ -648,7 +649,8 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
     const int c = J0 + i;
     const int rows_below = rlim - (c + 1);
     const bool last = i + 1 >= Wp;
-    const bool fused = !last && (h->opt_panel_chain & 4) != 0 && rows_below >= 1 && (long)rows_below * nb < h->opt_trsm128;
+    // (the link's ride solves any number of rows, 16 per workgroup; beyond link_rows 128-row blocks x members the stand-alone LDS-DMA solve is the better kernel)
+    const bool fused = !last && (h->opt_panel_chain & 4) != 0 && rows_below >= 1 && (long)rows_below * nb < h->opt_link_rows;
     if (!fused) {
       if ((rc = solve_column(c))) return rc;
       if (on_col && (rc = (*on_col)(c))) return rc;
@@ -1292,6 +1294,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "xcd_chunks")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_xcd_chunks = (int)value; return SIGP_OK; }
   if (!strcmp(name, "n64_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_n64_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "wide_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_wide_tiles = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "link_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_link_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_stored")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_stored = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
