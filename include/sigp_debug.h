@@ -9,6 +9,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* wall-clock phase stamps of one potrf_diag_kernel launch (tools/diag_phases.py) */
+int sigp_debug_diag_stamps(sigp_handle* h, const double* A128, double* out_us, int nout);
 /* time potrf_diag_kernel on one 128x128 SPD block; `skip` bit mask switches phases off (tools/diag_bench.py) */
 int sigp_debug_time_diag(sigp_handle* h, const double* A128, int skip, int reps, double* ms_avg, double* L_out, double* Linv_out);
 /* time the covariance build for nb lockstep members of order n; flags: 2 no covariance function, 4 no store (tools/kbuild_bench.py) */

@@ -39,6 +39,14 @@ template <typename T> constexpr int diag_lds_bytes() { return ((36 + DIAG_XT) * 
 constexpr int DIAG_LDS_BYTES = diag_lds_bytes<double>();
 constexpr int DIAG_THREADS = 512;
 
+#ifdef SIGP_DEBUG_TOOLS
+// tools/diag_phases.py: wall-clock stamps (s_memrealtime, 10 ns ticks) of the kernel's phases, written by wave 0 when bit 64 of `flags` is set
+__device__ unsigned long long g_diag_stamp[64];
+#define DIAG_STAMP(k) do { if ((flags & 64) && threadIdx.x == 0) { g_diag_stamp[(k)] = __builtin_amdgcn_s_memrealtime(); if ((k) == 0 || (k) == 44) g_diag_stamp[48 + ((k) != 0)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define DIAG_STAMP(k) do { } while (0)
+#endif
+
 __device__ inline double readlane_t(double x, int l) {
   int lo = __double2loint(x), hi = __double2hiint(x);
   lo = __builtin_amdgcn_readlane(lo, l);
@@ -70,6 +78,7 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
   volatile int* flag = (volatile int*)(dinv + DB);   // flag[b] = 1: tile (b, b) holds its inverse
 
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DIAG_STAMP(0);
   int lane = tid & 63;
   int lr = lane & 15, lq = lane >> 4;
   // latency chain on the critical path of every panel, co-resident with MFMA-saturating update waves: ask the instruction
@@ -79,17 +88,28 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
   }
 
   // ---- load the lower triangle of the block ----
+  // All sixteen 16-byte loads of a thread are issued before the first one is waited for (a load and its LDS store inside one predicated
+  // iteration were sixteen dependent global round trips: 7.5 of the kernel's 37 us, tools/diag_phases.py).  Lanes right of the diagonal
+  // load nothing: their addresses are clamped onto the diagonal pair and the values dropped.
+  {
+    constexpr int NIT = DB * (DB / 2) / DIAG_THREADS;
+    v2_t ldv[NIT];
 #pragma unroll
-  for (int it = 0; it < DB * (DB / 2) / DIAG_THREADS; ++it) {
-    const int idx = tid + it * DIAG_THREADS;
-    const int row = idx >> 6, cp = (idx & 63) * 2;
-    if (cp <= row && !(skip & 16)) {
-      const v2_t v = *(const v2_t*)(A + (long)row * lda + cp);
-      *(v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = v;
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * DIAG_THREADS;
+      const int row = idx >> 6, cp = min((idx & 63) * 2, row & ~1);
+      ldv[it] = (skip & 16) ? v2_t{(T)0, (T)0} : *(const v2_t*)(A + (long)row * lda + cp);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + it * DIAG_THREADS;
+      const int row = idx >> 6, cp = (idx & 63) * 2;
+      if (cp <= row && !(skip & 16)) *(v2_t*)(S + dblk(row >> 4, cp >> 4) + (row & 15) * BP + (cp & 15)) = ldv[it];
     }
   }
   if (tid < 8) flag[tid] = 0;
   __syncthreads();
+  DIAG_STAMP(1);
 
   // one tile of a rank-16 step:  Cd = Cs - A_ B_^T  (two tiles interleaved: one's MFMA chain hides behind the other's)
   auto upd2 = [&](const T* Cs0, T* Cd0, const T* A0, const T* B0, bool two, const T* Cs1, T* Cd1, const T* A1, const T* B1) {
@@ -126,6 +146,7 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
     T* tile = S + dblk(below ? bt : jb, jb);        // lanes without a row tile walk the diagonal tile too (results unused)
 #pragma unroll
     for (int c = 0; c < 16; ++c) r[c] = tile[lr * BP + c];
+    if (jb == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); DIAG_STAMP(50); }
     // Branch-free: the 16 pivots are ONE basic block, so the scheduler can run the tail of pivot j's column updates under the
     // reciprocal latency of pivot j+1.
     int bad = 0;          // first non-positive / NaN pivot of this tile (1-based), uniform
@@ -133,10 +154,11 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
     if (!(skip & 1))
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      T dj = readlane_t(r[j], j);
+      const T dj = readlane_t(r[j], j);
+      // a non-positive / NaN pivot is recorded, NOT replaced: its reciprocal poisons the rest of this member's factor (inf / NaN), which nobody
+      // reads once `info` is set -- the compare-and-select that kept the factor finite sat on the dependent chain of every pivot
       const bool neg = !(dj > (T)0);
       bad = (neg && bad == 0) ? j + 1 : bad;
-      dj = neg ? (T)1 : dj;
       myd = (lq == 0 && lr == j) ? dj : myd;
       T x = rcp_seed(dj);
       T e = fma(-dj, x, (T)1);
@@ -144,12 +166,19 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
       e = fma(-dj, x, (T)1);
       x = fma(x, e, x);                // 1 / d_j
       const T t = r[j] * x;            // u_ij / d_j
+      // the pivot column's entries four at a time into four scalar register pairs, then their four FMAs: with one pair reused for every entry each
+      // v_readlane pair / wait state / FMA triple was serialised on it (s_nop after every pair: ~20 cycles per entry, 355 per pivot -- tools/diag_phases.py)
 #pragma unroll
-      for (int c = j + 1; c < 16; ++c) {
-        const T ucj = readlane_t(r[j], c);
-        r[c] = fma(-t, ucj, r[c]);
+      for (int c0 = j + 1; c0 < 16; c0 += 4) {
+        T u[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) u[q] = (c0 + q < 16) ? readlane_t(r[j], c0 + q) : (T)0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (c0 + q < 16) r[c0 + q] = fma(-t, u[q], r[c0 + q]);
       }
     }
+    if (jb == 1) DIAG_STAMP(51);
     // 1 / sqrt(d) for the 16 pivots at once (lane j: d_j): v_rsq + two Goldschmidt steps
     const T y0 = rsq_seed(myd);
     T g = myd * y0, hh = (T)0.5 * y0;
@@ -161,17 +190,28 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
     const T sq = fma(e2, hh, g);       // sqrt(d)
     const T rs = hh + hh;              // 1 / sqrt(d)
 #pragma unroll
-    for (int j = 0; j < 16; ++j) r[j] *= readlane_t(rs, j);
+    for (int j0 = 0; j0 < 16; j0 += 4) {     // (four scalar register pairs in flight, as in the pivot loop)
+      T sc[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sc[q] = readlane_t(rs, j0 + q);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) r[j0 + q] *= sc[q];
+    }
+    if (jb == 1) DIAG_STAMP(52);
     if (below) {
 #pragma unroll
       for (int c = 0; c < 16; ++c) tile[lr * BP + c] = r[c];
     } else if (w == 0 && lq == 0) {    // the factored diagonal tile stays in wave 0's copy until commit_diag
       dinv[jb * 16 + lr] = rs;         // (first read by the tile inverse of the next slot)
+      // the whole row as it stands, then the diagonal entry over it: nothing reads the tile right of its diagonal before wave 7 overwrites it with
+      // the inverse (store_tile skips it, the tile inverse reads below the diagonal), and sixteen select pairs per lane were 0.3 us per column
 #pragma unroll
-      for (int c = 0; c < 16; ++c) XT[lr * BP + c] = (c < lr) ? r[c] : (c == lr ? sq : (T)0);
+      for (int c = 0; c < 16; ++c) XT[lr * BP + c] = r[c];
+      XT[lr * BP + lr] = sq;
     }
     // LAPACK info = index of the first failing pivot
     if (w == 0 && bad != 0 && lane == 0 && *info == 0) *info = pivot_base + jb * 16 + bad;
+    if (jb == 1) DIAG_STAMP(53);
   };
   auto commit_diag = [&](int jb) {     // wave 0: its copy of the factored diagonal tile -> the block
     if (wave == 0) {
@@ -193,7 +233,9 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
   };
 
   if (wave < 3) pivot_column(0, wave);
+  DIAG_STAMP(2);
   __syncthreads();
+  DIAG_STAMP(3);
 
   acc_t pend;               // an MFMA wave's finished inverse tile X(s, pend_j)^T, written before the next opening barrier
   int pend_j = -1;
@@ -211,6 +253,7 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
       pend_j = -1;
     }
     __syncthreads();
+    DIAG_STAMP(4 + 5 * s);
     const int jn = s + 1;                               // the block column the pivot waves work on in this slot
     // rank-16 update (column s) of block column jn, one tile per wave (the pivot loop needs all of them: with every SIMD's matrix
     // pipe on it the step is one 4-MFMA chain instead of up to four on the pivot wave's own)
@@ -218,11 +261,14 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
       T* Cn = S + dblk(jn + wave, jn);
       upd2(Cn, Cn, S + dblk(jn + wave, s), S + dblk(jn, s), false, Cn, Cn, S + dblk(jn + wave, s), S + dblk(jn, s));
     }
+    DIAG_STAMP(5 + 5 * s);
     if (s < 7) __syncthreads();
+    DIAG_STAMP(6 + 5 * s);
     const bool pivot_wave = s < 7 && (wave == 0 || (wave == 1 && s <= 2));
     if (pivot_wave) {
       const int w = wave;
       pivot_column(jn, w);
+      DIAG_STAMP(7 + 5 * s);
     } else if (wave == 7) {
       // row s of L -> global; inverse of the diagonal tile in place; row s-1 of the inverse -> workspace
       if (!(skip & 16)) store_tile(S + dblk(s, s), A + (long)(s * 16) * lda + s * 16, lda, true);
@@ -298,7 +344,9 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
       }
     }
     if (s < 7) __syncthreads();
+    DIAG_STAMP(8 + 5 * s);
   }
+  DIAG_STAMP(44);
 }
 
 template <typename T>
