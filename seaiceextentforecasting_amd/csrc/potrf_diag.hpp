@@ -159,7 +159,6 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
       // reads once `info` is set -- the compare-and-select that kept the factor finite sat on the dependent chain of every pivot
       const bool neg = !(dj > (T)0);
       bad = (neg && bad == 0) ? j + 1 : bad;
-      myd = (lq == 0 && lr == j) ? dj : myd;
       T x = rcp_seed(dj);
       T e = fma(-dj, x, (T)1);
       x = fma(x, e, x);
@@ -178,6 +177,9 @@ __device__ __forceinline__ void potrf_diag_body(T* __restrict__ A, long lda, T* 
           if (c0 + q < 16) r[c0 + q] = fma(-t, u[q], r[c0 + q]);
       }
     }
+    // lane j of the diagonal rows: d_j = its own r[j], untouched since pivot j-1 updated it (picked out once here: six instructions per pivot inside the loop)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) myd = (lr == j) ? r[j] : myd;
     if (jb == 1) DIAG_STAMP(51);
     // 1 / sqrt(d) for the 16 pivots at once (lane j: d_j): v_rsq + two Goldschmidt steps
     const T y0 = rsq_seed(myd);
