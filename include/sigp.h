@@ -274,6 +274,7 @@ int sigp_synchronize(sigp_handle* h);
  *   refine_iters [3]      fp32 engine: fp64 refinement steps at most; refine_tol_e [12]: stop once every residual is <= 1e-12 (0 = never early)
  *   refine_stored [1]     fp32 engine: the covariance build also writes K~ in fp64 (8 n^2 bytes per lockstep member, skipped above 40 GB) and the
  *                         refinement's residuals read it (HBM-bound) instead of recomputing n^2 covariances each; 0 = recompute (no extra memory)
+ *   refine_sym [1]        ... reading the stored lower triangle ONCE per residual (4 n^2 bytes; row and column sums of every tile from LDS), 0 = in two passes
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
  *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
  *   dist_panel_split [0]  sharded fit, panel exchange by ROW PIECES ("all-gather of block-row pieces"): the owner factors only the panel's W x W top

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gemm_mfma.hpp"
+#include "lane_ops.hpp"
 
 namespace sigp {
 
@@ -892,14 +893,128 @@ __global__ __launch_bounds__(256) void kres_lower_rows_kernel(const double* __re
     for (int r = 0; r < 4; ++r) part[((long)chunk_out * 4 + r) * ldp + i] = acc[r];
   }
 }
+// The same residual in ONE pass over the stored lower triangle (the two kernels above read it twice: 8 n^2 bytes per residual, this
+// one 4 n^2).  Workgroup (S, c) owns rows [256 S, +256) x columns [c jlen, +jlen) of the triangle and walks it in 64 x 64 tiles
+// staged in LDS (the next tile's 32 KB already in flight in registers); every tile below the diagonal is used twice from LDS,
+//   row sums     lane = row,    wave w the tile's columns 16 w ..: racc[row tile][r] += K[i][j] x[r][j]   (kept across the walk)
+//   column sums  lane = column, wave w the tile's rows 16 w ..:    cacc[r]           += K[i][j] x[r][i]   (kept across the 4 row tiles)
+// (a diagonal 64-tile is stored whole: row sums only), x through scalar loads (wave-uniform addresses).  No atomics -- every partial
+// has its own slot and krefine_finish_kernel adds them in slot order:
+//   slot c,        rows of S:             the row sums of (S, c)                       c <  nJ
+//   slot nJ + S,   columns of chunk c:    the column sums of (S, c)                    S <  nS
+// Entry i of a residual is the sum of slots c <= (256 S(i) + 255) / jlen and nJ + S, S >= S(i): exactly the slots written for it.
+// jlen is a multiple of 64; x beyond n is zero and the padded rows / columns of K~ are stored (identity), so no masks.
+constexpr int KSYM_LP = 65;
+template <int NR>                // right-hand sides carried (1, 2 or 4 >= nrhs)
+__global__ __launch_bounds__(256, 3) void kres_sym_kernel(const double* __restrict__ Kq, long ldk, int n_pad, int nrhs,
+                                                       const double* __restrict__ Xq, long ldq, double* __restrict__ part,
+                                                       long ldp, int jlen, int nJ) {
+  const int S = blockIdx.x, c = blockIdx.y;
+  if ((long)c * jlen > (long)S * 256 + 255) return;
+  __shared__ double T[64 * KSYM_LP];
+  __shared__ double red[4][4][64];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int It0 = 4 * S, nIt = min(4, n_pad / 64 - It0);          // row tiles It0 .. It0 + nIt - 1
+  const int Jt0 = c * (jlen / 64), Jt1 = min(min((c + 1) * (jlen / 64), It0 + nIt), n_pad / 64);
+  const int lrow = t >> 5, lcp = (t & 31) * 2;                    // the thread's piece of a tile: rows lrow + 8 k, columns lcp, lcp + 1
+  const int Ilast = n_pad / 64 - 1;
+  d2 pre[8];
+  double pxJ[NR], pxI[NR];                                        // x of the tile's columns / rows, lane l = entry l: fetched with the tile
+  // every (row tile, J) of the band is walked -- a tile right of the diagonal (the band's diagonal 256-block only) or below the
+  // matrix is fetched from a valid address and zeroed on its way into LDS: straight-line code, 0.6 % more bytes at n = 32768
+  auto issue = [&](int I, int J) {
+    const int Ic = min(I, Ilast), Jc = min(J, Ic);
+    const double* src = Kq + ((long)Ic * 64 + lrow) * ldk + (long)Jc * 64 + lcp;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pre[k] = *(const d2*)(src + (long)(8 * k) * ldk);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { pxJ[r] = Xq[(long)r * ldq + (long)J * 64 + lane]; pxI[r] = Xq[(long)r * ldq + (long)Ic * 64 + lane]; }
+  };
+  double racc[4][NR], cacc[NR];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) racc[a][r] = 0.0;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) cacc[r] = 0.0;
+  const int ntile = 4 * (Jt1 - Jt0);                              // the walk: J ascending, the band's four row tiles under each J
+  if (ntile > 0) issue(It0, Jt0);
+#pragma unroll 1
+  for (int q = 0; q < ntile; ++q) {
+    const int a = q & 3, J = Jt0 + (q >> 2), I = It0 + a;
+    const bool live = a < nIt && J <= I;                          // (uniform)
+    __syncthreads();                                              // the last tile's readers are done
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      T[(lrow + 8 * k) * KSYM_LP + lcp] = live ? pre[k].x : 0.0;
+      T[(lrow + 8 * k) * KSYM_LP + lcp + 1] = live ? pre[k].y : 0.0;
+    }
+    double xJ[NR], xI[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { xJ[r] = pxJ[r]; xI[r] = pxI[r]; }
+    __syncthreads();
+    if (q + 1 < ntile) issue(a < 3 ? I + 1 : It0, a < 3 ? J : J + 1);     // the next tile of the walk
+    {
+      double rt[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) rt[r] = 0.0;
+      const double* tr = T + lane * KSYM_LP + 16 * w;
+#pragma unroll
+      for (int jj = 0; jj < 16; ++jj) {
+        const double kv = tr[jj];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) rt[r] = fma(kv, readlane_t(xJ[r], 16 * w + jj), rt[r]);
+      }
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa)                              // (registers, not an indexed array: + 0.0 is exact)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) racc[aa][r] += (aa == a) ? rt[r] : 0.0;
+    }
+    if (J < I) {                                                  // (a diagonal tile is stored whole: its row sums are everything)
+      const double* tc = T + (16 * w) * KSYM_LP + lane;
+#pragma unroll
+      for (int ii = 0; ii < 16; ++ii) {
+        const double kv = tc[ii * KSYM_LP];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) cacc[r] = fma(kv, readlane_t(xI[r], 16 * w + ii), cacc[r]);
+      }
+    }
+    if (a == 3) {
+      // the column sums of tile column J over this workgroup's rows: waves in order, one slot entry each
+#pragma unroll
+      for (int r = 0; r < NR; ++r) { red[w][r][lane] = cacc[r]; cacc[r] = 0.0; }
+      __syncthreads();
+      const int r = t >> 6;
+      if (r < nrhs) part[((long)(nJ + S) * 4 + r) * ldp + (long)J * 64 + lane] = ((red[0][r][lane] + red[1][r][lane]) + red[2][r][lane]) + red[3][r][lane];
+    }
+  }
+  // the row sums: four waves' shares, through the tile's LDS
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) T[((w * 4 + a) * 4 + r) * 64 + lane] = racc[a][r];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int idx = q * 256 + t, a = idx >> 8, r = (idx >> 6) & 3;   // (a, r, lane)
+    if (a < nIt && r < nrhs) {
+      const double v = ((T[((0 * 4 + a) * 4 + r) * 64 + lane] + T[((1 * 4 + a) * 4 + r) * 64 + lane]) + T[((2 * 4 + a) * 4 + r) * 64 + lane]) +
+                       T[((3 * 4 + a) * 4 + r) * 64 + lane];
+      part[((long)c * 4 + r) * ldp + (long)(It0 + a) * 64 + lane] = v;
+    }
+  }
+}
 template <int DREG>
 __global__ __launch_bounds__(256) void krefine_finish_kernel(const double* __restrict__ X, const double* __restrict__ Xs,
                                                              const double* __restrict__ y, int dp, int n, int nrhs,
                                                              const double* __restrict__ part, long ldp, int nchunk,
-                                                             double* __restrict__ Rout, long ldr, KParams kp, int i0 = 0, int i1 = -1) {
+                                                             double* __restrict__ Rout, long ldr, KParams kp, int i0 = 0, int i1 = -1,
+                                                             int sym_jlen = 0, int sym_nS = 0) {
   const int i = i0 + blockIdx.x * 256 + threadIdx.x;
   if (i >= (i1 < 0 ? n : i1)) return;
-  for (int r = 0; r < nrhs; ++r) {
+  for (int r = blockIdx.y; r < nrhs; r += gridDim.y) {          // (gridDim.y = 1: every right-hand side in turn)
     double b;
     if (r == 0) {
       b = y[i];
@@ -912,9 +1027,42 @@ __global__ __launch_bounds__(256) void krefine_finish_kernel(const double* __res
       b = cov_from_sq(kp, sq);
     }
     double a = 0.0;
-    for (int c = 0; c < nchunk; ++c) a += part[((long)c * 4 + r) * ldp + i];
+    if (sym_nS > 0) {            // kres_sym_kernel's slots for entry i (nchunk = nJ)
+      const int Si = i >> 8, cmax = min(nchunk - 1, (int)(((long)Si * 256 + 255) / sym_jlen));
+      for (int c = 0; c <= cmax; ++c) a += part[((long)c * 4 + r) * ldp + i];
+      for (int S = Si; S < sym_nS; ++S) a += part[((long)(nchunk + S) * 4 + r) * ldp + i];
+    } else {
+      for (int c = 0; c < nchunk; ++c) a += part[((long)c * 4 + r) * ldp + i];
+    }
     Rout[(long)r * ldr + i] = b - a;
   }
+}
+
+// out[r] = max_i |R[r][i]| (r < nrhs), out[nrhs] = max_i |y[i]|: what the refinement's stopping test and its reported residual need --
+// 8 doubles to the host instead of the residual rows (pageable copies of (1 + m) n doubles cost 0.8 ms per test at n = 32768)
+__global__ __launch_bounds__(1024) void refine_norms_kernel(const double* __restrict__ R, long ldr, int n, int nrhs,
+                                                            const double* __restrict__ y, double* __restrict__ out) {
+  __shared__ double sh[16];
+  const int b = blockIdx.x;
+  const double* src = b < nrhs ? R + (long)b * ldr : y;
+  double m = 0.0;
+  for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(src[i]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 16; ++k) m = fmax(m, sh[k]);
+    out[b] = m;
+  }
+}
+
+// out[k] = sum_b part[b][k], k < 8: krefine_dots_kernel's block partials, added in block order (one wave)
+__global__ __launch_bounds__(64) void sum_parts8_kernel(const double* __restrict__ part, int nblk, double* __restrict__ out) {
+  if (threadIdx.x >= 8) return;
+  double a = 0.0;
+  for (int b = 0; b < nblk; ++b) a += part[(long)b * 8 + threadIdx.x];
+  out[threadIdx.x] = a;
 }
 
 // dst[r][i] (TO) <- src[r][i] (TI), rows x cols, different strides; zero beyond cols_valid

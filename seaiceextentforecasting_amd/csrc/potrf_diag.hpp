@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 
 #include "gemm_mfma.hpp"
+#include "lane_ops.hpp"
 
 namespace sigp {
 
@@ -47,13 +48,6 @@ __device__ unsigned long long g_diag_stamp[64];
 #define DIAG_STAMP(k) do { } while (0)
 #endif
 
-__device__ inline double readlane_t(double x, int l) {
-  int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_readlane(lo, l);
-  hi = __builtin_amdgcn_readlane(hi, l);
-  return __hiloint2double(hi, lo);
-}
-__device__ inline float readlane_t(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
 __device__ inline double rsq_seed(double x) { return __builtin_amdgcn_rsq(x); }
 __device__ inline float rsq_seed(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ inline double rcp_seed(double x) { return __builtin_amdgcn_rcp(x); }

@@ -96,6 +96,7 @@ struct sigp_handle {
   double* fpart = nullptr;   // partial sums of the final dots
   int opt_refine_iters = 3;
   int opt_refine_stored = 1; // fp32 fits: the covariance build also writes K~ in fp64 (8 n^2 bytes per member, up to 40 GB) and the refinement's residuals read it instead of recomputing it
+  int opt_refine_sym = 1;    // ... in ONE pass over the stored lower triangle (kres_sym_kernel); 0: two passes (kres_lower_cols / _rows)
   int opt_refine_tol_e = 12; // stop refining once every residual is below 10^-this (relative); 0 = always refine_iters steps
   double refine_resid = 0;   // ||y - K~ alpha~||_inf / ||y||_inf after the last refinement step
   std::vector<double> kss_unit;               // k~(xs,xs) per ride test point
@@ -544,8 +545,9 @@ int upload_kparams(sigp_handle* h, Slot& s, int nb, hipStream_t st = nullptr) {
 template <typename TO>
 void launch_kbuild(sigp_handle* h, dim3 grid, hipStream_t st, const double* X, long strideX, int dp, int d, int n, TO* Mat, long strideM, long ld,
                    const KParams* kps, int flags, int colblk0 = 0, double* Mat64 = nullptr, long stride64 = 0) {
-  if (h->opt_kbuild_mfma == 1 || (h->opt_kbuild_mfma == 2 && d >= 16)) {
+  if (h->opt_kbuild_mfma == 1 || h->opt_kbuild_mfma == 3 || (h->opt_kbuild_mfma == 2 && d >= 16)) {
     if (d <= 8) hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 8>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
+    else if (h->opt_kbuild_mfma == 3) hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 16>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
     else hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 32>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
     return;
   }
@@ -690,14 +692,18 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
 // ---- blocked Cholesky of the nb lockstep members of slot s (each augmented with its ride rows) --------
 // Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
 // GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
+// block columns per outer panel
+// (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
+//  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
+inline int outer_width(const sigp_handle* h, int nb, int T) {
+  return (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
+}
 template <typename Real>
 int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad, bool head_on_panel = false) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
-  // (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
-  //  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
-  const int W = (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
+  const int W = outer_width(h, nb, T);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
@@ -1269,7 +1275,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_tol_e")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_refine_tol_e = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
   if (!strcmp(name, "update_dbg")) { h->opt_update_dbg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "c_dma")) {
@@ -1296,6 +1302,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "wide_tiles")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_wide_tiles = (int)value; return SIGP_OK; }
   if (!strcmp(name, "link_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_link_rows = (int)value; return SIGP_OK; }
   if (!strcmp(name, "chain_rows")) { if (value < 0) return SIGP_BAD_ARG; h->opt_chain_rows = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "refine_sym")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_sym = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_stored")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_refine_stored = (int)value; return SIGP_OK; }
   if (!strcmp(name, "first_on_panel")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_first_on_panel = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_chain")) { if (value < 0 || value > 15) return SIGP_BAD_ARG; h->opt_panel_chain = (int)value; return SIGP_OK; }

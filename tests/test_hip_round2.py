@@ -473,29 +473,32 @@ def test_diagonal_block_kernel_reports_the_first_bad_pivot(S):
 
 def test_fp32_refinement_from_the_stored_fp64_matrix_equals_the_recomputed_one(S):
     """fp32 engine (BASELINE configs[4]): the covariance build writes K~ in fp64 beside the fp32 matrix and the refinement's residuals
-    r = b - K~ x read it in two coalesced passes over its lower triangle (kres_lower_cols / _rows) instead of recomputing n^2
-    covariances per residual (option refine_stored, default on).  Both ways refine the same systems to fp64 accuracy: solutions, nlML
+    r = b - K~ x read its lower triangle -- once (kres_sym_kernel, option refine_sym, default) or in two coalesced passes
+    (kres_lower_cols / _rows) -- instead of recomputing n^2 covariances per residual (option refine_stored, default on).  Both ways refine the same systems to fp64 accuracy: solutions, nlML
     and predictions agree to 1e-11 and with the oracle at the fp32 engine's tolerances -- ragged orders (chunk and block boundaries of
     both passes), 0..3 ride points, both kernels, a lockstep group, and one handle reused for a smaller problem after a larger one."""
     cases = [(37, 3, 0, "rbf"), (255, 5, 1, "matern52"), (256, 4, 2, "rbf"), (257, 9, 3, "matern52"), (1000, 8, 2, "rbf"), (2311, 32, 1, "matern52"),
-             (4100, 16, 2, "matern52"), (700, 6, 2, "rbf")]
+             (4100, 16, 2, "matern52"), (700, 6, 2, "rbf"), (8300, 8, 0, "rbf")]
     with S.GPR(kernel="rbf", dtype="f32") as keep_rbf, S.GPR(kernel="matern52", dtype="f32") as keep_mat:
         for n, d, m, kind in cases:
             X, y, Xs = O.synthetic_problem(n, d, 4000 + n, m=max(m, 1))
             Xs = Xs[:m] if m else None
             ell, sn = float(np.sqrt(d)), 0.1
             got = []
-            for stored in (1, 0):
+            for stored, sym in ((1, 1), (0, 1), (1, 0)):     # one pass over the stored triangle (kres_sym_kernel, default) / recomputed / two passes
                 gp = keep_mat if kind == "matern52" else keep_rbf
                 gp.set_option("refine_stored", stored)
+                gp.set_option("refine_sym", sym)
                 gp.fit(X, y, ell, sn, Xs=Xs)
                 mu, var = gp.predict(Xs) if m else (np.zeros(0), np.zeros(0))
                 got.append((gp.alpha_.copy(), gp.nlml_, gp.sigma_f_, mu, var, gp.refine_residual_))
-            a1, a0 = got
-            assert rel(a1[0], a0[0]) <= 1e-11 and rel(a1[1], a0[1]) <= 1e-12 and rel(a1[2], a0[2]) <= 1e-12, (n, kind)
-            if m:
-                assert rel(a1[3], a0[3]) <= 1e-11 and rel(a1[4], a0[4]) <= 1e-10, (n, kind)
-            assert 0 <= a1[5] <= 1e-10 and 0 <= a0[5] <= 1e-10
+            a1, a0, a2 = got
+            for ax in (a0, a2):
+                assert rel(a1[0], ax[0]) <= 1e-11 and rel(a1[1], ax[1]) <= 1e-12 and rel(a1[2], ax[2]) <= 1e-12, (n, kind)
+                if m:
+                    assert rel(a1[3], ax[3]) <= 1e-11 and rel(a1[4], ax[4]) <= 1e-10, (n, kind)
+                assert 0 <= ax[5] <= 1e-10
+            assert 0 <= a1[5] <= 1e-10
             ref = O.fit_predict(X, y, Xs if m else X[:1], ell, sn, kind=kind, ref_idiom=False)
             assert rel(a1[0], ref["alpha"]) <= 1e-6 and rel(a1[1], ref["nlml"]) <= 5e-5, (n, kind)
             if m:

@@ -6,12 +6,14 @@ import numpy as np
 from oracle import gp_oracle as O
 from seaiceextentforecasting_amd import GPR
 
+VAR = tuple(int(v) for v in os.environ.get("KBUILD_AB_VARIANTS", "0,1").split(","))     # values of option kbuild_mfma to compare (3 = 16-feature chunks)
+
 def batch(n, d, G, kern):
     Xb = np.zeros((G, n, d)); yb = np.zeros((G, n)); Xsb = np.zeros((G, 1, d))
     for b in range(G):
         Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 20240002 + b, m=1)
     ell = np.full(G, np.sqrt(d)); sn = np.full(G, 1e-2)
-    for mf in (0, 1, 0, 1):
+    for mf in VAR + VAR:
         with GPR(kernel=kern) as gp:
             gp.set_option("kbuild_mfma", mf)
             gp.upload_batch(Xb, yb, Xsb, group=G, concurrency=1)
@@ -25,7 +27,7 @@ def batch(n, d, G, kern):
 def single(n, d, kern, dtype, sn):
     X, y, Xs = O.synthetic_problem(n, d, 20240004, m=1)
     K = {}
-    for mf in (0, 1, 0, 1):
+    for mf in VAR + VAR:
         with GPR(kernel=kern, dtype=dtype) as gp:
             gp.set_option("kbuild_mfma", mf)
             gp.fit(X, y, np.sqrt(d), sn, Xs=Xs)
@@ -35,8 +37,9 @@ def single(n, d, kern, dtype, sn):
             mu, var = gp.predict(Xs)
             K[mf] = (mu[0], var[0], gp.nlml_)
         print("single n=%d d=%d %s %s kbuild_mfma=%d: kbuild %.3f ms, fit %.2f ms, mean %.15g var %.15g nlml %.15g" % (n, d, kern, dtype, mf, p["ms"], dt * 1e3, *K[mf]), flush=True)
-    print("   relative difference mfma vs valu: mean %.2e var %.2e nlml %.2e" % tuple(abs(a - b) / abs(b) for a, b in zip(K[1], K[0])), flush=True)
+    print("   relative difference %d vs %d: mean %.2e var %.2e nlml %.2e" % ((VAR[1], VAR[0]) + tuple(abs(a - b) / abs(b) for a, b in zip(K[VAR[1]], K[VAR[0]]))), flush=True)
 
-batch(8192, 8, 40, "rbf")
+if 3 not in VAR:
+    batch(8192, 8, 40, "rbf")
 single(8192, 32, "matern52", "f64", 1e-2)
 single(32768, 32, "matern52", "f32", 1e-1)

@@ -7,6 +7,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=16384); ap.add_argument("--d", type=int, default=16); ap.add_argument("--dtype", default="f64")
 ap.add_argument("--kernel", default="rbf"); ap.add_argument("--sn", type=float, default=1e-2); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--single", action="store_true"); ap.add_argument("--rccl", action="store_true"); ap.add_argument("--outer", type=int, default=8)
+ap.add_argument("--opt", action="append", default=[], help="name=value engine option (single-GPU entry), repeatable")
 a = ap.parse_args()
 from seaiceextentforecasting_amd import GPR, DistributedGPR
 rng = np.random.default_rng(20240003)
@@ -14,11 +15,14 @@ X = rng.standard_normal((a.n, a.d)); w = rng.standard_normal(a.d) / np.sqrt(a.d)
 ell = np.sqrt(a.d)
 if a.single:
     with GPR(kernel=a.kernel, dtype=a.dtype, outer_blocks=a.outer) as g:
+        for o in a.opt:
+            g.set_option(o.split("=")[0], int(o.split("=")[1]))
         g.fit(X, y, ell, a.sn, Xs=Xs)
         ts = []
         for _ in range(a.reps):
             t0 = time.perf_counter(); g.refit(ell, a.sn); ts.append(time.perf_counter() - t0)
-    print("single-GPU entry: best %.3f ms, all %s" % (1e3 * min(ts), [round(1e3 * t, 2) for t in ts]))
+        extra = " refine_residual %.2e nlml %.10e" % (g.refine_residual_, g.nlml_) if a.dtype == "f32" else ""
+    print("single-GPU entry %s: best %.3f ms, all %s%s" % (a.opt, 1e3 * min(ts), [round(1e3 * t, 2) for t in ts], extra))
 else:
     with DistributedGPR(a.kernel, 0, 1, None, outer_blocks=a.outer, dtype=a.dtype, stats=True, force_rccl=a.rccl) as g:
         g.fit(X, y, ell, a.sn, Xs=Xs)
