@@ -545,9 +545,8 @@ int upload_kparams(sigp_handle* h, Slot& s, int nb, hipStream_t st = nullptr) {
 template <typename TO>
 void launch_kbuild(sigp_handle* h, dim3 grid, hipStream_t st, const double* X, long strideX, int dp, int d, int n, TO* Mat, long strideM, long ld,
                    const KParams* kps, int flags, int colblk0 = 0, double* Mat64 = nullptr, long stride64 = 0) {
-  if (h->opt_kbuild_mfma == 1 || h->opt_kbuild_mfma == 3 || (h->opt_kbuild_mfma == 2 && d >= 16)) {
+  if (h->opt_kbuild_mfma == 1 || (h->opt_kbuild_mfma == 2 && d >= 16)) {
     if (d <= 8) hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 8>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
-    else if (h->opt_kbuild_mfma == 3) hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 16>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
     else hipLaunchKernelGGL((kbuild_mfma_kernel<TO, 32>), grid, dim3(256), 0, st, X, strideX, dp, d, n, Mat, strideM, ld, kps, flags, colblk0, Mat64, stride64);
     return;
   }
@@ -695,7 +694,10 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
 // block columns per outer panel
 // (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
 //  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
-inline int outer_width(const sigp_handle* h, int nb, int T) {
+// (a single fp32 fit from 192 block columns on: the fp32 update runs its K = 1024 tile in half the time of the fp64 one, so the tile's C read +
+//  write weighs twice as much -- K = 2048 instead: n = 32768 102.95 vs 104.4 ms (12: 103.3, 24: 104.1, 32: 106.3); n = 16384 19.2 vs 19.05: not there)
+inline int outer_width(const sigp_handle* h, int nb, int T, bool f32 = false) {
+  if (!h->outer_set && nb == 1 && f32 && T >= 192) return 16;
   return (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
 }
 template <typename Real>
@@ -703,7 +705,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
-  const int W = outer_width(h, nb, T);
+  const int W = outer_width(h, nb, T, std::is_same<Real, float>::value);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
@@ -1275,7 +1277,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_tol_e")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_refine_tol_e = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
-  if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 3) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
   if (!strcmp(name, "update_dbg")) { h->opt_update_dbg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "c_dma")) {

@@ -6,7 +6,7 @@ import numpy as np
 from oracle import gp_oracle as O
 from seaiceextentforecasting_amd import GPR
 
-VAR = tuple(int(v) for v in os.environ.get("KBUILD_AB_VARIANTS", "0,1").split(","))     # values of option kbuild_mfma to compare (3 = 16-feature chunks)
+VAR = tuple(int(v) for v in os.environ.get("KBUILD_AB_VARIANTS", "0,1").split(","))     # values of option kbuild_mfma to compare
 
 def batch(n, d, G, kern):
     Xb = np.zeros((G, n, d)); yb = np.zeros((G, n)); Xsb = np.zeros((G, 1, d))
@@ -39,7 +39,6 @@ def single(n, d, kern, dtype, sn):
         print("single n=%d d=%d %s %s kbuild_mfma=%d: kbuild %.3f ms, fit %.2f ms, mean %.15g var %.15g nlml %.15g" % (n, d, kern, dtype, mf, p["ms"], dt * 1e3, *K[mf]), flush=True)
     print("   relative difference %d vs %d: mean %.2e var %.2e nlml %.2e" % ((VAR[1], VAR[0]) + tuple(abs(a - b) / abs(b) for a, b in zip(K[VAR[1]], K[VAR[0]]))), flush=True)
 
-if 3 not in VAR:
-    batch(8192, 8, 40, "rbf")
+batch(8192, 8, 40, "rbf")
 single(8192, 32, "matern52", "f64", 1e-2)
 single(32768, 32, "matern52", "f32", 1e-1)

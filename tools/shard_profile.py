@@ -6,7 +6,7 @@ import numpy as np
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=16384); ap.add_argument("--d", type=int, default=16); ap.add_argument("--dtype", default="f64")
 ap.add_argument("--kernel", default="rbf"); ap.add_argument("--sn", type=float, default=1e-2); ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--single", action="store_true"); ap.add_argument("--rccl", action="store_true"); ap.add_argument("--outer", type=int, default=8)
+ap.add_argument("--single", action="store_true"); ap.add_argument("--rccl", action="store_true"); ap.add_argument("--outer", type=int, default=None, help="outer panel width in 128-column blocks (default: the engine's choice)")
 ap.add_argument("--opt", action="append", default=[], help="name=value engine option (single-GPU entry), repeatable")
 a = ap.parse_args()
 from seaiceextentforecasting_amd import GPR, DistributedGPR
@@ -24,7 +24,7 @@ if a.single:
         extra = " refine_residual %.2e nlml %.10e" % (g.refine_residual_, g.nlml_) if a.dtype == "f32" else ""
     print("single-GPU entry %s: best %.3f ms, all %s%s" % (a.opt, 1e3 * min(ts), [round(1e3 * t, 2) for t in ts], extra))
 else:
-    with DistributedGPR(a.kernel, 0, 1, None, outer_blocks=a.outer, dtype=a.dtype, stats=True, force_rccl=a.rccl) as g:
+    with DistributedGPR(a.kernel, 0, 1, None, outer_blocks=a.outer or 8, dtype=a.dtype, stats=True, force_rccl=a.rccl) as g:
         g.fit(X, y, ell, a.sn, Xs=Xs)
         ts = []
         for _ in range(a.reps):

@@ -53,7 +53,7 @@ try:
     fs = pd.read_csv(base + "f32_stats/f32_kernel_stats.csv")
     fs = fs[fs["Name"].str.contains("syrk128_kernel<float, false", regex=False)]
     n = 32768
-    f32 = {"kernel": "sigp::syrk128_kernel<float, false, false> (trailing + in-panel updates of one fp32 Cholesky, n = 32768, outer panels of 8 x 128)",
+    f32 = {"kernel": "sigp::syrk128_kernel<float, false, false> (trailing + in-panel updates of one fp32 Cholesky, n = 32768, outer panels of 16 x 128: K = 2048)",
            "command": "rocprofv3 --pmc <C> / --kernel-trace --stats -- python3 tools/shard_profile.py --single --dtype f32 --n 32768 --d 32 --kernel matern52 --sn 0.1 --reps 2",
            "launches_per_run": int(len(ff)), "fetch_bytes_total_corrected": float(ff["Counter_Value"].sum()) * 1024 * 2, "write_bytes_total": float(fw["Counter_Value"].sum()) * 1024,
            "stats_total_ms": float(fs["TotalDurationNs"].iloc[0]) / 1e6, "stats_calls": int(fs["Calls"].iloc[0]), "fits_in_run": 3,
