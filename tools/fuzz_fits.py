@@ -19,8 +19,9 @@ def run(cases, seed, verbose=True):
       kind = str(rng.choice(["rbf", "matern52"]))
       dtype = "f32" if (rng.random() < 0.25 and d <= 64 and m <= 3) else "f64"
       W = int(rng.choice([1, 2, 3, 4, 8, 16]))
-      opts = {"panel_chain": int(rng.choice([0, 1, 3])), "first_on_panel": int(rng.choice([0, 1, 2])), "lookahead": int(rng.choice([0, 1, 1])),
-              "chain_rows": int(rng.choice([0, 8, 80, 1000]))}
+      opts = {"panel_chain": int(rng.choice([0, 1, 3, 5, 7, 8, 15, 15])), "first_on_panel": int(rng.choice([0, 1, 2])), "lookahead": int(rng.choice([0, 1, 1])),
+              "chain_rows": int(rng.choice([0, 8, 80, 1000])), "link_rows": int(rng.choice([0, 16, 256, 4096])), "kbuild_mfma": int(rng.choice([0, 1, 2])),
+              "refine_sym": int(rng.choice([0, 1, 1]))}
       X, y, Xs = O.synthetic_problem(n, d, 1000 + case, m=max(m, 1))
       Xs = Xs[:m] if m else None
       ell = float(np.sqrt(d) * 10 ** rng.uniform(-0.5, 0.5)); sn = float(10 ** rng.uniform(-2, 0))
