@@ -1,7 +1,7 @@
 """Randomised sharded fits (sigp_dist_fit) against the oracle, every rank checking its own copy of the results:
     python -m torch.distributed.run --nproc-per-node W --master-addr 127.0.0.1 tools/fuzz_sharded.py [cases] [seed]
 Ranks share the box's GPU (host-pointer transport over gloo).  Random order n (block-boundary cases included), feature count, ride
-rows, kernel, precision, panel width (1..9 blocks, also wider than the matrix), look-ahead on/off."""
+rows, kernel, precision, panel width (1..9 blocks, also wider than the matrix), look-ahead on/off, panel exchange whole / by row pieces."""
 import os, sys, time
 import torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,7 +24,7 @@ for case in range(cases):
     d = int(rng.integers(1, 33)); m = int(rng.integers(0, 4))
     kind = str(rng.choice(["rbf", "matern52", "netdiffusion"]))
     dtype = "f32" if (kind != "netdiffusion" and rng.random() < 0.4) else "f64"
-    W = int(rng.integers(1, 10)); la = bool(rng.integers(0, 2))
+    W = int(rng.integers(1, 10)); la = bool(rng.integers(0, 2)); split = bool(rng.integers(0, 2))      # panel exchange: whole-panel broadcast / row pieces + all-gather
     X, y, Xs = O.synthetic_problem(n, d, 7000 + case + 1000 * seed, m=max(m, 1))
     Xs = Xs[:m] if m else None
     if kind == "netdiffusion":
@@ -32,7 +32,7 @@ for case in range(cases):
     else:
         ell, sn = float(np.sqrt(d) * 10 ** rng.uniform(-0.4, 0.4)), float(10 ** rng.uniform(-2 if dtype == "f64" else -1, 0))
     ref = O.fit_predict(X, y, Xs if m else X[:1], ell, sn, kind=kind, ref_idiom=False)
-    with DistributedGPR(kind, rank, world, dist if world > 1 else None, outer_blocks=W, lookahead=la, dtype=dtype) as dg:
+    with DistributedGPR(kind, rank, world, dist if world > 1 else None, outer_blocks=W, lookahead=la, dtype=dtype, panel_split=split) as dg:
         dg.fit(X, y, ell, sn, Xs=Xs)
         got = {"nlml": dg.nlml_, "sigma_f": dg.sigma_f_}
         if m:
