@@ -694,10 +694,10 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
 // block columns per outer panel
 // (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
 //  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
-// (a single fp32 fit from 192 block columns on: the fp32 update runs its K = 1024 tile in half the time of the fp64 one, so the tile's C read +
+// (fp32 fits from 192 block columns on: the fp32 update runs its K = 1024 tile in half the time of the fp64 one, so the tile's C read +
 //  write weighs twice as much -- K = 2048 instead: n = 32768 102.95 vs 104.4 ms (12: 103.3, 24: 104.1, 32: 106.3); n = 16384 19.2 vs 19.05: not there)
 inline int outer_width(const sigp_handle* h, int nb, int T, bool f32 = false) {
-  if (!h->outer_set && nb == 1 && f32 && T >= 192) return 16;
+  if (!h->outer_set && f32 && T >= 192) return 16;             // (a lockstep group of 4 at n = 32768: 97.7 vs 98.6-99.0 ms per fit)
   return (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
 }
 template <typename Real>
