@@ -65,6 +65,17 @@ try:
         f32["mfma_pipe_busy_fraction"] = float(fm["SQ_VALU_MFMA_BUSY_CYCLES"] / (fm["GRBM_GUI_ACTIVE"] / 8 * 1024))
     except Exception:
         pass
+    # the other HBM-side kernels of the same run: the refinement's one-pass residual and the fp32 build (bytes per launch from the same passes)
+    fe_all = pd.read_csv(base + "f32_pmc_FETCH_SIZE/f32_counter_collection.csv"); wr_all = pd.read_csv(base + "f32_pmc_WRITE_SIZE/f32_counter_collection.csv")
+    st_all = pd.read_csv(base + "f32_stats/f32_kernel_stats.csv")
+    for key, alg in (("kres_sym_kernel", 4.0 * n * n), ("kbuild_mfma_kernel", 2.0 * n * (n + 1) + 4.0 * n * (n + 1) + 8.0 * n * 32)):
+        sel2 = lambda df, col: df[df[col].str.contains(key, regex=False)]
+        fk2, wk2, sk2 = sel2(fe_all, "Kernel_Name"), sel2(wr_all, "Kernel_Name"), sel2(st_all, "Name")
+        if len(fk2) and len(sk2):
+            ms = float(sk2["AverageNs"].iloc[0]) / 1e6
+            fb, wb = float(fk2["Counter_Value"].mean()) * 1024 * 2, float(wk2["Counter_Value"].mean()) * 1024
+            f32[key] = {"launches_pmc": int(len(fk2)), "fetch_bytes_per_launch_corrected": fb, "write_bytes_per_launch": wb, "algorithmic_bytes_per_launch": alg,
+                        "rocprofv3_stats_avg_ms": ms, "hbm_total_GBps": (fb + wb) / (ms * 1e-3) / 1e9}
     json.dump(f32, open("profiles/%s_pmc_syrk128_f32.json" % rnd, "w"), indent=1)
     print("syrk128<float>: %.1f TFLOP/s in-kernel (%.2f of peak), fetch %.1f GB, write %.1f GB per run" % (f32["tflops_in_kernel"], f32["frac_of_fp32_mfma_peak"], f32["fetch_bytes_total_corrected"] / 1e9, f32["write_bytes_total"] / 1e9))
 except FileNotFoundError as e:
