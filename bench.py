@@ -96,7 +96,7 @@ def spawn_ranks(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="timed steps; a step = one lockstep batch of --group fits (all years at one grid point)")
+    ap.add_argument("--steps", type=int, default=2, help="timed steps; a step = one lockstep batch of --group fits (all years at group / years consecutive grid points)")
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=8192)
     ap.add_argument("--d", type=int, default=8)
@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--grid", choices=["smoke", "full"], default="smoke", help="hyper-parameter grid the steps walk: 4x4 or 20x20 over the SURVEY 8(d) ranges")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--concurrency", type=int, default=1, help="lockstep groups in flight")
-    ap.add_argument("--group", type=int, default=40, help="fits factorised in lockstep per launch")
+    ap.add_argument("--group", type=int, default=160, help="fits factorised in lockstep per launch: 160 = the 40 years at 4 grid points (86 GB of matrices; 40: 325, 80: 333, 120: 335, 160: 336.5, 240: 337 fits/s on one box)")
     ap.add_argument("--outer", type=int, default=8, help="outer panel width in 128-column blocks (K of the trailing update = 128*outer)")
     ap.add_argument("--host-timing", action="store_true")
     ap.add_argument("--opt", action="append", default=[], help="engine option name=value (repeatable)")
@@ -151,19 +151,21 @@ def main():
     years = max(1, args.years)
     G = max(1, args.group)                   # fits per step
     total_steps = args.warmup + args.steps
-    # ---- which fits this rank runs.  Global fit i (step s = i // G) = year i % years at grid point s. -----------------
+    # ---- which fits this rank runs.  Global fit i = year i % years at grid point i // years; step s = fits [s G, (s + 1) G). -----------------
     if args.scaling == "weak" or world == 1:
         # every rank: its own `years` data sets (different seeds), all steps
         my_years = list(range(years))
         seeds = [20240002 + 1000 * rank + b for b in my_years]
         my_fits = np.arange(total_steps * G)
         fit_step = my_fits // G
+        fit_point = my_fits // years
         n_warm = args.warmup * G
     else:
         # strong: the fixed job of steps x G fits is dealt round-robin; the warm-up steps are dealt the same way
         all_fits = np.arange(total_steps * G)
         mine = all_fits[rank::world]
         fit_step = mine // G
+        fit_point = mine // years
         yr = mine % years
         period = len(np.unique(yr))          # the rank's year sequence is periodic (years / gcd(world, years))
         assert np.array_equal(yr, np.tile(yr[:period], len(yr) // period + 1)[:len(yr)])
@@ -174,8 +176,8 @@ def main():
     Xb = np.zeros((len(my_years), n, d)); yb = np.zeros((len(my_years), n)); Xsb = np.zeros((len(my_years), m, d))
     for j, sd in enumerate(seeds):
         Xb[j], yb[j], Xsb[j] = synthetic_problem(n, d, sd, m=m)
-    ell = np.array([grid_point(int(s), d, args.grid)[0] for s in fit_step])
-    sn = np.array([grid_point(int(s), d, args.grid)[1] for s in fit_step])
+    ell = np.array([grid_point(int(s), d, args.grid)[0] for s in fit_point])
+    sn = np.array([grid_point(int(s), d, args.grid)[1] for s in fit_point])
     K, W = len(my_fits) - n_warm, n_warm    # this rank's timed / warm-up FITS
 
     gp = GPR(kernel="rbf", device=local, outer_blocks=args.outer)
@@ -278,8 +280,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(1, args.steps), "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "configs[2]: n=%d d=%d fp64 RBF GPR, batch of retrospective years x hyper-parameter grid (%s: %dx%d over l = sqrt(d) logspace(-1,1), sn~ = logspace(-3,1)), "
-                               "one step = the %d years at one grid point factorised in lockstep, each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1"
-                               % (n, d, args.grid, len(grid_axes(d, args.grid)[0]), len(grid_axes(d, args.grid)[1]), G),
+                               "one step = %d fits factorised in lockstep (the %d years at %s consecutive grid points), each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1"
+                               % (n, d, args.grid, len(grid_axes(d, args.grid)[0]), len(grid_axes(d, args.grid)[1]), G, years, ("%g" % (G / years))),
                    "n": n, "d": d, "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / max(1, fits // world if args.scaling == "weak" else fits), "years_resident_per_rank": len(my_years),
                    "lockstep_group": args.group, "groups_in_flight": args.concurrency, "grid": args.grid,
                    "parallelism": ("years sharded over %d GPU(s): every rank its own %d years, no data-path collective" % (world, years)) if args.scaling == "weak" else
@@ -316,7 +318,7 @@ def main():
                     continue
                 try:
                     pm = json.load(open(pth))
-                    if n == 8192 and d == 8 and args.group == 40 and args.outer == 8:
+                    if n == 8192 and d == 8 and args.group == pm.get("lockstep_group", 40) and args.outer == 8:     # (per-launch bytes scale with the members per launch)
                         if pm.get("kernel_code_sha16") == kernel_code_sha16():
                             out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
                             out["roofline"]["traffic_source"] = ("from profiles/%s_pmc_syrk128.json (rocprofv3 --pmc passes of this command on this kernel code, sha16 %s; NOT this run): "
@@ -382,8 +384,8 @@ def compact_line(out):
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     c = {k: out.get(k) for k in keep}
     cfg = out.get("config", {})
-    c["config"] = {"workload": "configs[2]: n=%s d=%s fp64 RBF GPR, %s retrospective years x hyper-parameter grid, one step = the years at one grid point in lockstep"
-                               % (cfg.get("n"), cfg.get("d"), cfg.get("fits_per_step")),
+    c["config"] = {"workload": "configs[2]: n=%s d=%s fp64 RBF GPR, %s retrospective years x hyper-parameter grid, one step = fits_per_step fits in lockstep"
+                               % (cfg.get("n"), cfg.get("d"), cfg.get("years_resident_per_rank")),
                    "fits_per_step": cfg.get("fits_per_step"), "grid": cfg.get("grid"), "parallelism": "years sharded over %s GPU(s), no data-path collective" % out.get("n_gpus")}
     rf = out.get("roofline")
     if rf:

@@ -37,8 +37,9 @@ A("**Headline** (`profiles/%s_bench_line_verbose.json`, the default `python benc
 A("")
 A("| quantity | value | source |")
 A("|---|---|---|")
-A("| GP fits/s, configs[2] (n = %d, d = %d, 40 years in lockstep per step) | **%.1f** (%.2f ms per 40-fit step; %.1f without the event brackets) | `value`, `ms_per_step`, `without_event_brackets` |"
-  % (v["config"]["n"], v["config"]["d"], v["value"], v["ms_per_step"], v.get("without_event_brackets", {}).get("value", float("nan"))))
+G = int(v["config"]["fits_per_step"]); YR = int(v["config"].get("years_resident_per_rank", 40))
+A("| GP fits/s, configs[2] (n = %d, d = %d; a step = %d fits in lockstep: the %d years at %g consecutive grid points) | **%.1f** (%.2f ms per %d-fit step; %.1f without the event brackets) | `value`, `ms_per_step`, `without_event_brackets` |"
+  % (v["config"]["n"], v["config"]["d"], G, YR, G / YR, v["value"], v["ms_per_step"], G, v.get("without_event_brackets", {}).get("value", float("nan"))))
 A("| whole fit, fraction of the fp64 MFMA peak (78.6 TFLOP/s) | %.3f (%.1f TFLOP/s) | `whole_fit_frac_of_fp64_mfma_peak` |" % (v["whole_fit_frac_of_fp64_mfma_peak"], v["whole_fit_tflops"]))
 A("| `roofline`: `syrk128_kernel<double>` by HIP events over the timed region | **%.3f** = %.2f TFLOP/s; %d launches, avg %.3f ms, %.4g flop each | `roofline` |"
   % (rf["frac"], rf["achieved"], rf["launches"], rf["avg_launch_ms"], rf["flops_per_launch"]))
@@ -52,8 +53,8 @@ A("| CPU baseline (oracle in the reference's call sequence, %d BLAS threads, 1 w
   % (cb["cores"], cb["value"], cb["seconds"], v["cpu_baseline_best_practice"]["seconds"], v["vs_cpu_baseline"]))
 pr = v["parity"]
 A("| parity of the first timed step vs the oracle (mean / variance / nlML, relative) | %.1e / %.1e / %.1e (tolerance 1e-8) | `parity` |" % (pr["batch_step0_mean_rel"], pr["batch_step0_var_rel"], pr["batch_step0_nlml_rel"]))
-A("| covariance build `kbuild_kernel<double,8>`, 40 members per launch | %.3f ms; %.2f GB written + %.2f GB fetched (PMC) = %.2f TB/s = %.2f of 8 TB/s; algorithmic %.2f GB -> %.2f TB/s | `profiles/%s_pmc_kbuild.json` |"
-  % (kb["rocprofv3_stats_avg_ms"], kb["write_bytes_per_launch"] / 1e9, kb["fetch_bytes_per_launch_corrected"] / 1e9, kb["hbm_total_GBps"] / 1e3, kb["frac_of_8TBps"], kb["algorithmic_bytes_per_launch"] / 1e9,
+A("| covariance build `kbuild_kernel<double,8>`, %d members per launch | %.3f ms; %.2f GB written + %.2f GB fetched (PMC) = %.2f TB/s = %.2f of 8 TB/s; algorithmic %.2f GB -> %.2f TB/s | `profiles/%s_pmc_kbuild.json` |"
+  % (G, kb["rocprofv3_stats_avg_ms"], kb["write_bytes_per_launch"] / 1e9, kb["fetch_bytes_per_launch_corrected"] / 1e9, kb["hbm_total_GBps"] / 1e3, kb["frac_of_8TBps"], kb["algorithmic_bytes_per_launch"] / 1e9,
      kb["algorithmic_bytes_per_launch"] / (kb["rocprofv3_stats_avg_ms"] * 1e-3) / 1e12, R))
 A("| `syrk128_kernel<float>` over all launches of a configs[4] fit | %.1f TFLOP/s = %.3f of 157.3; matrix pipe busy %s | `profiles/%s_pmc_syrk128_f32.json` |"
   % (f32["tflops_in_kernel"], f32["frac_of_fp32_mfma_peak"], ("%.3f" % f32["mfma_pipe_busy_fraction"]) if "mfma_pipe_busy_fraction" in f32 else "n/a", R))

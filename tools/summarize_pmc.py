@@ -5,9 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 base = "gpurun_out/%s/" % rnd
-out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 --no-profile  (one pass per counter set)",
+out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --no-profile  (one pass per counter set; default lockstep group)",
        "kernel": "sigp::syrk128_kernel<double, false, false>", "notes": [],
        "kernel_code_sha16": bench.kernel_code_sha16()}      # bench.py quotes roofline.traffic from this file only while the kernel code is the same
+try:
+    G = int(json.load(open(base + "bench.json"))["config"]["fits_per_step"])      # lockstep members per launch of the profiled bench command
+except Exception:
+    G = 160
+out["lockstep_group"] = G
 sel = lambda df: df[df["Kernel_Name"].str.contains("syrk128_kernel<double, false", regex=False)]   # the trailing / inner updates (not the SET = true panel solve)
 fe = sel(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
 wr = sel(pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv"))
@@ -34,10 +39,10 @@ fk = selk(pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"))
 wk = selk(pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv"))
 st = pd.read_csv(base + "stats/bench_kernel_stats.csv")
 st = st[st["Name"].str.contains("kbuild_kernel<double", regex=False)]
-kb = {"kernel": "sigp::kbuild_kernel<double, 8> (RBF covariance build of 40 lockstep members, lower 64x128 tiles, n = 8192, d = 8)",
+kb = {"kernel": "sigp::kbuild_kernel<double, 8> (RBF covariance build of %d lockstep members, lower 64x128 tiles, n = 8192, d = 8)" % G,
       "launches_pmc": int(len(wk)), "write_bytes_per_launch": float(wk["Counter_Value"].mean()) * 1024,
       "fetch_bytes_per_launch_corrected": float(fk["Counter_Value"].mean()) * 1024 * 2,
-      "algorithmic_bytes_per_launch": 40 * (4.0 * 8192 * 8193 + 8.0 * 8192 * 8),
+      "algorithmic_bytes_per_launch": G * (4.0 * 8192 * 8193 + 8.0 * 8192 * 8),
       "rocprofv3_stats_avg_ms": float(st["AverageNs"].iloc[0]) / 1e6, "rocprofv3_stats_calls": int(st["Calls"].iloc[0])}
 kb["hbm_write_GBps"] = kb["write_bytes_per_launch"] / (kb["rocprofv3_stats_avg_ms"] * 1e-3) / 1e9
 kb["hbm_total_GBps"] = (kb["write_bytes_per_launch"] + kb["fetch_bytes_per_launch_corrected"]) / (kb["rocprofv3_stats_avg_ms"] * 1e-3) / 1e9
