@@ -150,6 +150,28 @@ def main():
     n, d, m = args.n, args.d, 1
     years = max(1, args.years)
     G = max(1, args.group)                   # fits per step
+    G_asked = G
+    # the group's matrices are ONE allocation of G (n + 128) n doubles (86 GB at the defaults): on a GPU that does not have that much free
+    # (shared box, another tenant) fall back to fewer grid points per launch instead of failing -- the record says so
+    try:
+        import ctypes
+        from seaiceextentforecasting_amd import _lib as _L
+        hip = ctypes.CDLL(_L.runtime_info().split(" from ")[-1].strip())      # the runtime already mapped into this process (never a second one)
+        free_b, total_b = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        ndev = ctypes.c_int(0)
+        if hip.hipSetDevice(int(local)) == 0 and hip.hipMemGetInfo(ctypes.byref(free_b), ctypes.byref(total_b)) == 0 and hip.hipGetDeviceCount(ctypes.byref(ndev)) == 0:
+            per_member = (n + 128) * n * 8.0 * 1.02
+            reserve = 70e9 if not args.no_extras else 8e9          # the untimed extras (fp32 group of 4, MLII group of 40) allocate beside it
+            share = -(-world // max(1, ndev.value))                # ranks of a rehearsal that share this GPU (1 in a real launch)
+            while G > years and G * per_member + reserve > free_b.value / share:
+                G -= years
+    except Exception:
+        pass
+    if dist is not None:                                           # every rank runs the same group (the smallest any of them can hold)
+        tg = torch.tensor([G], dtype=torch.int64, device=("cuda" if backend == "nccl" else "cpu"))
+        dist.all_reduce(tg, op=dist.ReduceOp.MIN)
+        G = int(tg.item())
+    args.group = G
     total_steps = args.warmup + args.steps
     # ---- which fits this rank runs.  Global fit i = year i % years at grid point i // years; step s = fits [s G, (s + 1) G). -----------------
     if args.scaling == "weak" or world == 1:
@@ -283,7 +305,7 @@ def main():
                                "one step = %d fits factorised in lockstep (the %d years at %s consecutive grid points), each fit = kernel build + blocked Cholesky + sigma_f/nlML + predict m=1"
                                % (n, d, args.grid, len(grid_axes(d, args.grid)[0]), len(grid_axes(d, args.grid)[1]), G, years, ("%g" % (G / years))),
                    "n": n, "d": d, "fits_per_step": G, "ms_per_fit": 1e3 * elapsed / max(1, fits // world if args.scaling == "weak" else fits), "years_resident_per_rank": len(my_years),
-                   "lockstep_group": args.group, "groups_in_flight": args.concurrency, "grid": args.grid,
+                   "lockstep_group": args.group, "lockstep_group_asked": G_asked, "groups_in_flight": args.concurrency, "grid": args.grid,
                    "parallelism": ("years sharded over %d GPU(s): every rank its own %d years, no data-path collective" % (world, years)) if args.scaling == "weak" else
                                   ("the fixed %d-fit job dealt round-robin over %d GPU(s), no data-path collective" % (fits, world))},
         "whole_fit_tflops": value * flops_fit / 1e12 / world,
