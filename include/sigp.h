@@ -127,6 +127,17 @@ int sigp_small_upload(sigp_handle* h, int64_t nsets, const int64_t* n, const int
                       const double* lam_pool, const int64_t* lam_off);
 int sigp_small_run(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde,
                    double* out, double* mean, double* var, int64_t mstride);
+/* The same launch with the MLII closure's second return value (north/June1st.py:235-257, the call the reference left commented out at
+ * :259-262 `minimize(MLII, x0, method='CG', jac=True)`), for every (data set, theta) of the list at once: out8 [nprob][8] =
+ * sigma_f, nlML, info, sigma_n, then the reference's own 2-vector "gradient" (:248-252: tr(K^-1 dK)/2 - alpha^T dK alpha/2 with
+ * dKdl = X (M Sigma) X^T + sigma_n I, dKds = X Sigma X^T + sigma_f I -- NOT the derivative of nlML), then the exact
+ * derivative of the profiled nlML w.r.t. (log l, log sn~).  A non-SPD K~ gives +inf in all of them (:254-256).  The inverse factor
+ * L~^-1 is formed in LDS over L~; M Sigma~ = Q diag(lam exp(l lam)) Q^T needs no second matrix (lam_mode 0).  Sets staged with
+ * lam_mode 1 (weights of a host-side Pade expm) need the derivative weights dlam_k = u_k^T M u_k * lam_k, given once per upload by
+ * sigp_small_set_dweights (dlam_pool mirrors lam_pool: same offsets, `count` = its total length); without them their gradient is NaN. */
+int sigp_small_set_dweights(sigp_handle* h, const double* dlam_pool, int64_t count);
+int sigp_small_run_grad(sigp_handle* h, int64_t nprob, const int64_t* set_index, const double* ell, const double* sn_tilde,
+                        double* out8, double* mean, double* var, int64_t mstride);
 
 /* The caller that produces the GP's features: ComplexNetworks.Network.tau (ComplexNetworks.py:31-47) on the device.
  * series [N][T] (row stride lds): the anomaly series of the N active grid cells.  Forms the N x N cell-to-cell correlation matrix

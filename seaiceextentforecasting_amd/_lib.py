@@ -43,6 +43,8 @@ SIGNATURES = {
     "sigp_batch_run": (C.c_int, [_h, _i64, _i64, C.c_int, _dp, _dp, C.c_int, _dp, _dp, _dp]),
     "sigp_small_upload": (C.c_int, [_h, _i64, _ip64, _ip64, _ip64, _ip32, _dp, _ip64, _dp, _ip64, _dp, _ip64]),
     "sigp_small_run": (C.c_int, [_h, _i64, _ip64, _dp, _dp, _dp, _dp, _dp, _i64]),
+    "sigp_small_set_dweights": (C.c_int, [_h, _dp, _i64]),
+    "sigp_small_run_grad": (C.c_int, [_h, _i64, _ip64, _dp, _dp, _dp, _dp, _dp, _i64]),
     "sigp_get_stat": (C.c_int, [_h, C.c_char_p, _dp]),
     "sigp_area_sums": (C.c_int, [_h, _dp, _i64, _i64, _dp, _ip32, _i64, _dp]),
     "sigp_area_level": (C.c_int, [_dp, _i64, _ip32, _i64, _i64, C.c_int32, C.c_double, C.c_int, _ip32, _ip64, _ip32, _ip64, _ip32, _i64, _ip64]),

@@ -112,6 +112,7 @@ struct sigp_handle {
   double* sm_A = nullptr; long cap_sm_A = 0;
   double* sm_y = nullptr; long cap_sm_y = 0;
   double* sm_lam = nullptr; long cap_sm_lam = 0;
+  double* sm_dlam = nullptr; long cap_sm_dlam = 0; long sm_lam_len = 0; bool sm_has_dlam = false;   // lam_mode 1: derivative weights
   SmallProb* sm_probs = nullptr; long cap_sm_probs = 0;
   double* sm_out = nullptr; long cap_sm_out = 0;   // [nprob][4 + 2*mstride]
   int sm_ch = 32, sm_mmax = 0, sm_nmax = 0; long sm_lds = 0;
@@ -1230,7 +1231,7 @@ int sigp_destroy(sigp_handle* h) {
   (void)hipDeviceSynchronize();
   prof_drain(h);
   for (auto& s : h->slots) slot_free(s);
-  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->rpart, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_out};
+  double* bufs[] = {h->X, h->y, h->Xs, h->scratchZ, h->T, h->Sig, h->XsA, h->stage, h->bX, h->by, h->bXs, h->gU, h->gK, h->gD, h->gPart, h->gSig, h->gT, h->xq, h->rq, h->rpart, h->fpart, h->sm_A, h->sm_y, h->sm_lam, h->sm_dlam, h->sm_out};
   dist_release(h);
   if (h->sm_sets_dev) (void)hipFree(h->sm_sets_dev);
   if (h->sm_probs) (void)hipFree(h->sm_probs);

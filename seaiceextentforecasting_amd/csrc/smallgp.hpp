@@ -40,7 +40,7 @@ struct SmallProb {
 
 inline long smallgp_lds_bytes(int n, int m, int ch) {
   const long ldk = n | 1;
-  return ((long)(n + 1 + m) * ldk + (long)(n + m) * (ch + 1) + ch + 4 * SM_MMAX + 16) * (long)sizeof(double);
+  return ((long)(n + 1 + m) * ldk + (long)(n + m) * (ch + 1) + ch + 4 * SM_MMAX + 16 + n) * (long)sizeof(double);
 }
 
 // sum over the NT threads of the workgroup; result valid on every thread
@@ -57,16 +57,29 @@ __device__ inline double smallgp_allsum(double v, double* sh) {
   return t;
 }
 
-// out [nprob][4] = sigma_f, nlML, info (LAPACK pivot index, 0 = ok), sigma_n;  mean / var [nprob][mstride]
+// out [nprob][OW]: OW = 4 (GRAD = false): sigma_f, nlML, info (LAPACK pivot index, 0 = ok), sigma_n;  mean / var [nprob][mstride]
+// OW = 8 (GRAD = true): the same four, then the reference's MLII "gradient" (north/June1st.py:248-252) and the exact derivative of
+// the profiled nlML w.r.t. (log l, log sn~).  In factored form every matrix of :248-252 is a reweighting of the same A:
+//     dKdl = X (M Sigma) X^T + sigma_n I = sigma_f (D1 + sn~ I),  D1 = A diag(dw) A^T,  dw_k = lam_k exp(l lam_k)   (M Sigma~ = Q diag(lam w) Q^T)
+//     dKds = X Sigma X^T + sigma_f I     = sigma_f (K~ - sn~ I + I),      K^-1 = K~^-1 / sigma_f,  alpha = a~ / sigma_f,
+// so with T0 = tr(K~^-1), T1 = tr(K~^-1 D1), q0 = a~.a~, q1 = a~^T D1 a~ :
+//     ref   g1 = (T1 + sn~ T0)/2 - (q1 + sn~ q0)/(2 sigma_f)        g2 = (1 - sn~)(T0 - q0/sigma_f)/2      (a~^T y = n sigma_f)
+//     exact g1 = l (T1 - q1/sigma_f)/2                              g2 = sn~ (T0 - q0/sigma_f)/2
+// T0, T1 come from the explicit inverse factor X = L~^-1 (formed in place over L~, row by row): T0 = |X|_F^2,
+// T1 = sum_c dw_c |X a_c|^2 (a_c = column c of A; X a_c is never stored), a~ = X^T z, q1 = sum_c dw_c (a_c.a~)^2.
+// lam_mode 1 sets (weights from a host-side Pade expm) take dw from the `dlam` pool (sigp_small_set_dweights); without it their
+// gradient entries are NaN.
 // NT = threads per workgroup: 256 (four wavefronts per fit) is the default at every order; NT = 64 (one wavefront per fit, every
 // barrier of the column loop a wave-local no-op) is kept as a measurement switch ("small_nt64") -- on the reference-size grid it
 // is SLOWER (1.71 vs 1.02 ms for 48 000 fits of n = 6 .. 45): the rank-1 updates have ~n^2/2 elements, enough for four waves,
 // and one resident wave per fit leaves the LDS pipeline idle between dependent steps.
-template <int NT>
+template <int NT, bool GRAD = false>
 __global__ __launch_bounds__(NT) void smallgp_kernel(const SmallSet* __restrict__ sets, const SmallProb* __restrict__ probs,
                                                       const double* __restrict__ Apool, const double* __restrict__ ypool,
                                                       const double* __restrict__ lampool, int ch, double* __restrict__ out,
-                                                      double* __restrict__ mean, double* __restrict__ var, int mstride) {
+                                                      double* __restrict__ mean, double* __restrict__ var, int mstride,
+                                                      const double* __restrict__ dlampool) {
+  constexpr int OW = GRAD ? 8 : 4;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const SmallProb pb = probs[blockIdx.x];
   const SmallSet st = sets[pb.set];
@@ -157,7 +170,7 @@ __global__ __launch_bounds__(NT) void smallgp_kernel(const SmallSet* __restrict_
   const double inf = __builtin_huge_val(), qnan = __builtin_nan("");
   const double sf = zz / (double)n;
   if (tid == 0) {
-    double* o = out + (long)blockIdx.x * 4;
+    double* o = out + (long)blockIdx.x * OW;
     if (info == 0) {
       o[0] = sf;
       o[1] = 0.5 * n + logdet + 0.5 * n * log(sf) + 0.5 * n * log(2.0 * M_PI);
@@ -165,6 +178,7 @@ __global__ __launch_bounds__(NT) void smallgp_kernel(const SmallSet* __restrict_
       o[3] = sf * pb.sn;
     } else {
       o[0] = inf; o[1] = inf; o[2] = (double)info; o[3] = inf;
+      if (GRAD) { o[4] = inf; o[5] = inf; o[6] = inf; o[7] = inf; }     // north/June1st.py:254-256
     }
   }
   for (int j = 0; j < m; ++j) {
@@ -176,6 +190,87 @@ __global__ __launch_bounds__(NT) void smallgp_kernel(const SmallSet* __restrict_
     if (tid == 0) {
       mean[(long)blockIdx.x * mstride + j] = info == 0 ? vz : qnan;
       var[(long)blockIdx.x * mstride + j] = info == 0 ? sf * (kss[j] + pb.sn - vv) : qnan;
+    }
+  }
+
+  if constexpr (GRAD) {
+    if (info != 0) return;           // uniform
+    double* at = red + 16;           // [n] a~ = L~^-T z
+    // ---- X = L~^-1 in place, row by row: X(i,j) = -X(i,i) sum_{k=j}^{i-1} L(i,k) X(k,j); rows above i are complete, row i of L~ is
+    // read by everyone before anyone overwrites it.  Element j of the row belongs to a 16-lane group (k split over its lanes).
+    for (int i = 0; i < n; ++i) {
+      const double xii = 1.0 / Kp[i * ldk + i];
+      constexpr int MC = (SM_NMAX + TY - 1) / TY;
+      double mine[MC];
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const int j = ty + c * TY;
+        if (j < i) {
+          double acc = 0.0;
+          for (int k = j + tx; k < i; k += 16) acc = fma(Kp[i * ldk + k], Kp[k * ldk + j], acc);
+#pragma unroll
+          for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+          mine[c] = -xii * acc;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < MC; ++c) {
+        const int j = ty + c * TY;
+        if (j < i && tx == 0) Kp[i * ldk + j] = mine[c];
+      }
+      if (tid == 0) Kp[i * ldk + i] = xii;
+      __syncthreads();
+    }
+    for (int i = tid; i < n; i += NT) {
+      double a = 0.0;
+      for (int k = i; k < n; ++k) a = fma(Kp[k * ldk + i], z[k], a);
+      at[i] = a;
+    }
+    double t0 = 0.0, t1 = 0.0, q0 = 0.0, q1 = 0.0;
+    for (int e = tid; e < n * n; e += NT) {
+      const int i = e / n, j = e - i * n;
+      if (j <= i) { const double x = Kp[i * ldk + j]; t0 = fma(x, x, t0); }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) q0 = fma(at[i], at[i], q0);
+    const double* dlam = dlampool ? dlampool + st.lam_off : nullptr;
+    for (int k0 = 0; k0 < N; k0 += ch) {
+      const int kc = min(ch, N - k0);
+      __syncthreads();
+      if (tid < kc) {
+        const double l = lam[k0 + tid];
+        wk[tid] = st.lam_mode ? (dlam ? dlam[k0 + tid] : qnan) : l * exp(pb.ell * l);
+      }
+      for (int e = tid; e < n * kc; e += NT) {
+        const int r = e / kc, k = e - r * kc;
+        Ac[r * lda + k] = A[(long)r * N + k0 + k];
+      }
+      __syncthreads();
+      for (int e = tid; e < n * kc; e += NT) {
+        const int i = e / kc, c = e - i * kc;
+        const double* xi = Kp + i * ldk;
+        double v = 0.0;
+        for (int k = 0; k <= i; ++k) v = fma(xi[k], Ac[k * lda + c], v);
+        t1 = fma(wk[c] * v, v, t1);
+      }
+      if (tid < kc) {
+        double b = 0.0;
+        for (int i = 0; i < n; ++i) b = fma(Ac[i * lda + tid], at[i], b);
+        q1 = fma(wk[tid] * b, b, q1);
+      }
+    }
+    const double T0 = smallgp_allsum<NT>(t0, red);
+    const double T1 = smallgp_allsum<NT>(t1, red);
+    const double Q0 = smallgp_allsum<NT>(q0, red);
+    const double Q1 = smallgp_allsum<NT>(q1, red);
+    if (tid == 0) {
+      double* o = out + (long)blockIdx.x * OW;
+      const double sn = pb.sn;
+      o[4] = 0.5 * (T1 + sn * T0) - 0.5 * (Q1 + sn * Q0) / sf;
+      o[5] = 0.5 * (1.0 - sn) * (T0 - Q0 / sf);
+      o[6] = 0.5 * pb.ell * (T1 - Q1 / sf);
+      o[7] = 0.5 * sn * (T0 - Q0 / sf);
     }
   }
 }

@@ -400,8 +400,23 @@ class GPR:
         self._fitted = False
         return res
 
-    def upload_batch(self, X, y, Xs, group=8, concurrency=1):
-        """Stage data sets in HBM and allocate the lockstep slots without running any fit (bench warm-up)."""
+    def upload_batch(self, X, y, Xs, group=8, concurrency=1, M=None):
+        """Stage data sets in HBM and allocate the lockstep slots without running any fit (bench warm-up).
+        Reference kernel: X / y / Xs / M are sequences of ragged data sets (n <= 128 rows each: the retro years), kept as a
+        ``SmallBatch`` whose data stay resident for ``nlml_batch`` / ``optimize_batch``."""
+        if self.kernel == "netdiffusion":
+            from .smallbatch import SmallBatch
+            if isinstance(X, np.ndarray) and X.ndim == 2:
+                X, y, Xs, M = [X], [y], [Xs], [M]
+            B = len(X)
+            Xs = [None] * B if Xs is None else list(Xs)
+            M = [None] * B if M is None else list(M)
+            if len(y) != B or len(Xs) != B or len(M) != B:
+                raise ValueError("X, y, Xs and M must have one entry per data set (%d)" % B)
+            sb = SmallBatch(self)
+            self._small_ids = [sb.add_dataset(X[b], y[b], Xs[b], M[b]) for b in range(B)]
+            self._small = sb
+            return
         X = L.f64(X)
         Xb = X[None] if X.ndim == 2 else X
         B, n, d = Xb.shape
@@ -434,19 +449,51 @@ class GPR:
         return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
                     mean=mean[:, :mdim], var=var[:, :mdim])
 
-    def nlml_batch(self, theta, first=0, grad="exact", group=8):
-        """``MLII`` for many (data set, theta) pairs in lockstep on the data sets staged by ``upload_batch`` / ``fit_batch``
-        (RBF / Matern): theta [F, 2] = (log l, log sn~), pair i uses data set (first + i) % B.  Returns (nlml [F], grad [F, 2]
-        or None): the exact derivative of the profiled nlML (north/June1st.py:235-257 with the true gradient), +inf where K~
-        is not SPD.  One device call: this is what an optimiser over all retrospective years evaluates per iteration."""
-        if self.kernel == "netdiffusion":
-            raise ValueError("nlml_batch covers the RBF / Matern kernels (the reference kernel at reference size: nlml_grid / SmallBatch)")
-        if grad not in (None, "exact"):
-            raise ValueError("grad must be None or 'exact'")
+    def nlml_batch(self, theta, first=0, grad="exact", group=8, expm="eigh", sets=None):
+        """``MLII`` for many (data set, theta) pairs in one device call on the data sets staged by ``upload_batch`` / ``fit_batch``:
+        theta [F, 2] = (log l, log sn~), pair i uses data set (first + i) % B.  Returns (nlml [F], grad [F, 2] or None), +inf where K~
+        is not SPD or exp(theta) overflows (north/June1st.py:254-256).  This is what an optimiser over all retrospective years
+        evaluates per iteration (the reference's commented-out call, :259-262).
+
+        RBF / Matern: lockstep groups on the blocked engine; grad = 'exact' (the derivative of the profiled nlML) or None.
+        Reference kernel (n <= 128 per data set): one workgroup per pair, one launch (``sigp_small_run_grad``); grad = 'ref'
+        reproduces the reference's own formulae (:248-252), 'exact' the true derivative.  ``expm`` = 'eigh' (default: one
+        eigendecomposition of M per data set, nothing but theta crosses the bus per call) or 'pade' (scipy's expm per pair on
+        the host, the reference's own numbers at extreme l); ``sets`` [F] names the data set of every pair explicitly."""
         theta = L.f64(np.atleast_2d(theta), 2)
         if theta.shape[1] != 2:
             raise ValueError("theta must be [F, 2]")
         F = theta.shape[0]
+        if self.kernel == "netdiffusion":
+            if grad not in (None, "ref", "exact"):
+                raise ValueError("grad must be None, 'ref' or 'exact'")
+            sb = getattr(self, "_small", None)
+            if sb is None:
+                raise RuntimeError("nlml_batch: stage the data sets with upload_batch(X_list, y_list, Xs_list, M=M_list) first")
+            B = len(self._small_ids)
+            with np.errstate(over="ignore"):
+                ell, sn = np.exp(theta[:, 0]), np.exp(theta[:, 1])
+            ok = np.isfinite(ell) & np.isfinite(sn) & (ell > 0)
+            val = np.full(F, np.inf)
+            g = np.full((F, 2), np.inf)
+            sb.clear_fits()
+            run = []
+            for i in np.flatnonzero(ok):
+                try:
+                    sb.add_fit(self._small_ids[(first + i) % B if sets is None else int(sets[i])], ell[i], sn[i], expm=expm)
+                    run.append(i)
+                except (FloatingPointError, OverflowError, ValueError):       # scipy's expm overflowed: the except branch of :254-256
+                    pass
+            if run:
+                r = sb.run(grad=grad is not None)
+                val[run] = r["nlml"]
+                if grad is not None:
+                    g[run] = r["grad_ref" if grad == "ref" else "grad_exact"]
+            return val, (g if grad is not None else None)
+        if grad not in (None, "exact"):
+            raise ValueError("grad must be None or 'exact'")
+        if sets is not None:
+            raise ValueError("sets= is for the reference kernel's ragged data sets; the lockstep groups pair theta i with data set (first + i) % B")
         self.set_option("group", group)
         val = np.zeros(F)
         g = np.zeros((F, 2))
@@ -455,63 +502,34 @@ class GPR:
         self._fitted = False
         return val, (g if grad is not None else None)
 
-    def optimize_batch(self, X, y, theta0, group=8, maxiter=50, gtol=1e-5, ftol=1e-10, max_step=2.0):
+    def optimize_batch(self, X, y, theta0, group=8, maxiter=50, gtol=1e-5, ftol=1e-10, max_step=2.0, M=None, expm="eigh", method=None):
         """The reference's commented-out ``minimize(MLII, x0, method='CG', jac=True)`` (north/June1st.py:259-262) for EVERY data set
         of a retrospective run at once: X [B, n, d], y [B, n], theta0 [B, 2] (or [2]) -> dict(x [B, 2], fun [B], nit [B],
-        converged [B], nfev = device calls).  BFGS on the 2-vector (log l, log sn~) per data set, Armijo backtracking; the state of
-        every data set lives on the host and each round evaluates ONE trial point per unfinished data set in a single lockstep
-        device call (``nlml_batch``): the years advance together whatever their individual line searches do."""
+        converged [B], nfev = device calls).  The state of every data set lives on the host and each round is ONE device call for all
+        unfinished data sets: the years advance together whatever their individual line searches do (``optim.py``).
+
+        RBF / Matern (``method='bfgs'``): BFGS on the 2-vector (log l, log sn~) per data set with Armijo backtracking, one trial point
+        per data set and round in lockstep groups (``nlml_batch``).
+        Reference kernel (``method='newton'``): X / y (/ M) are sequences of ragged data sets (the 3 regions x years of
+        September1st_retro.py:176-180); a round is ONE launch of one workgroup per point, value + exact gradient formed in LDS, and since
+        extra points are free there each round carries several step lengths and their finite-difference neighbours: a modified-Newton
+        iteration with the line search inside the launch."""
+        from .optim import bfgs_lockstep, newton_lockstep
+        if self.kernel == "netdiffusion":
+            self.upload_batch(X, y, None, M=M)
+            B = len(self._small_ids)
+            th0 = np.broadcast_to(np.asarray(theta0, dtype=np.float64), (B, 2))
+            if (method or "newton") == "newton":
+                return newton_lockstep(lambda t, own: self.nlml_batch(t, grad="exact", expm=expm, sets=own), th0, maxiter=maxiter, gtol=gtol,
+                                       ftol=min(ftol, 1e-12), max_step=max_step)
+            return bfgs_lockstep(lambda t: self.nlml_batch(t, grad="exact", expm=expm), th0, maxiter=maxiter, gtol=gtol, ftol=ftol, max_step=max_step)
+        if (method or "bfgs") != "bfgs":
+            raise ValueError("method='newton' needs the one-workgroup-per-point kernel (reference kernel); RBF / Matern take 'bfgs'")
         X = L.f64(X, 3)
         B = X.shape[0]
         self.upload_batch(X, y, None, group=group, concurrency=1)
-        th = np.broadcast_to(np.asarray(theta0, dtype=np.float64), (B, 2)).copy()
-        f, g = self.nlml_batch(th, grad="exact", group=group)
-        nfev = 1
-        H = np.tile(np.eye(2), (B, 1, 1))
-        done = ~np.isfinite(f)
-        nit = np.zeros(B, dtype=np.int64)
-        step = np.ones(B)
-        direction = np.zeros((B, 2))
-        trial = th.copy()
-        new_dir = np.ones(B, dtype=bool)
-        for _ in range(maxiter * 8):
-            act = np.flatnonzero(~done)
-            if act.size == 0:
-                break
-            for b in act:
-                if new_dir[b]:
-                    p = -H[b] @ g[b]
-                    if p @ g[b] >= 0:                     # not a descent direction: reset the inverse Hessian
-                        H[b] = np.eye(2); p = -g[b]
-                    nrm = np.linalg.norm(p)
-                    if nrm > max_step:                    # log-space steps of at most max_step
-                        p *= max_step / nrm
-                    direction[b] = p; step[b] = 1.0; new_dir[b] = False
-                trial[b] = th[b] + step[b] * direction[b]
-            trial[done] = th[done]                         # finished data sets ride along at their optimum: one lockstep call per round
-            fa, ga = self.nlml_batch(trial, grad="exact", group=group)
-            ft, gt = fa[act], ga[act]
-            nfev += 1
-            for k, b in enumerate(act):
-                slope = g[b] @ direction[b]
-                if np.isfinite(ft[k]) and ft[k] <= f[b] + 1e-4 * step[b] * slope:
-                    s_ = trial[b] - th[b]; yv = gt[k] - g[b]
-                    df = f[b] - ft[k]
-                    th[b], f[b], g[b] = trial[b].copy(), ft[k], gt[k]
-                    nit[b] += 1
-                    sy = s_ @ yv
-                    if sy > 1e-12:
-                        rho = 1.0 / sy
-                        V = np.eye(2) - rho * np.outer(s_, yv)
-                        H[b] = V @ H[b] @ V.T + rho * np.outer(s_, s_)
-                    new_dir[b] = True
-                    if np.max(np.abs(g[b])) <= gtol or df <= ftol * max(1.0, abs(f[b])) or nit[b] >= maxiter:
-                        done[b] = True
-                else:
-                    step[b] *= 0.5
-                    if step[b] < 1e-8:
-                        done[b] = True
-        return dict(x=th, fun=f, nit=nit, nfev=nfev, converged=np.array([np.isfinite(f[b]) and np.max(np.abs(g[b])) <= max(gtol, 1e-3 * max(1.0, abs(f[b]))) for b in range(B)]), jac=g)
+        th0 = np.broadcast_to(np.asarray(theta0, dtype=np.float64), (B, 2))
+        return bfgs_lockstep(lambda t: self.nlml_batch(t, grad="exact", group=group), th0, maxiter=maxiter, gtol=gtol, ftol=ftol, max_step=max_step)
 
     def nlml_grid(self, X, y, ells, sns, concurrency=2, group=8, M=None):
         """nlML on the (l, sn~) grid for one data set -- the offline 20x20 search implied by

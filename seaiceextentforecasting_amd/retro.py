@@ -109,6 +109,49 @@ def retro_grid_search(script, SIC, SIEs_dt, fmin, fmax, SST=None, ells=LGRID, sn
             gp.close()
 
 
+def retro_optimise(script, SIC, SIEs_dt, fmin, fmax, SST=None, SIEs_trend=None, gp=None, theta0=None, expm="eigh", **kw):
+    """The optimiser call the reference left commented out (north/June1st.py:259-262, `minimize(MLII, x0, method='CG', jac=True)`
+    with x0 = log of the script's table entries), re-enabled for EVERY (region, year) of the retro loop
+    (September1st_retro.py:176-180) at once: each optimiser round is one device launch, one workgroup per (region, year), with
+    nlML (:246) and its exact gradient formed in LDS (``GPR.optimize_batch``; the reference's own "gradient" formulae, :248-252,
+    are not a derivative -- SURVEY App. C-7 -- and are available through ``nlml_batch(grad='ref')``).
+    Returns {region: dict(x [n_years, 2] = (log l, log sn~), fun, nit, converged)} and ``nfev`` (device launches); with
+    ``SIEs_trend`` also the forecast at each optimum in the reference's GPR-dict layout (``_fmean``, ``_fvar``, ``_fmean_rt``,
+    rounded as :241-244)."""
+    tab = SCRIPT_TABLE[script]
+    own = gp is None
+    gp = gp or GPR(kernel="netdiffusion")
+    try:
+        ny = fmax - fmin + 1
+        Xl, yl, Xsl, Ml, x0 = [], [], [], [], []
+        for k, region in enumerate(tab["regions"]):
+            for year in range(fmin, fmax + 1):
+                _, y, sic, sst = _retro_inputs(tab, SIC, SIEs_dt, SST, region, year, fmin)
+                X, Xs, M = _problem(tab, k, y, sic, sst)
+                Xl.append(X); yl.append(y); Xsl.append(Xs); Ml.append(M)
+                x0.append([np.log(tab["ell"][k]), np.log(tab["sn"][k])])
+        x0 = np.asarray(x0) if theta0 is None else np.broadcast_to(np.asarray(theta0, dtype=np.float64), (len(Xl), 2))
+        res = gp.optimize_batch(Xl, yl, x0, M=Ml, expm=expm, **kw)
+        out = {"nfev": res["nfev"]}
+        for k, region in enumerate(tab["regions"]):
+            sl = slice(k * ny, (k + 1) * ny)
+            out[region] = dict(x=res["x"][sl], fun=res["fun"][sl], nit=res["nit"][sl], converged=res["converged"][sl])
+        if SIEs_trend is not None:
+            th = res["x"]
+            r = gp.fit_batch(Xl, yl, Xsl, np.exp(th[:, 0]), np.exp(th[:, 1]), M=Ml)
+            for k, region in enumerate(tab["regions"]):
+                fmean, fvar = np.round(r["mean"][k * ny:(k + 1) * ny, 0], 3), np.round(r["var"][k * ny:(k + 1) * ny, 0], 3)
+                fmean_rt = np.zeros(ny)
+                for year in range(fmin, fmax + 1):
+                    row, i = year - (fmin - 1) - 1, year - fmin
+                    fmean_rt[i] = (fmean[i] + (year - 1979) * SIEs_trend[region][row, 0] + SIEs_trend[region][row, 1]).round(3)
+                out[region + "_fmean"], out[region + "_fvar"], out[region + "_fmean_rt"] = fmean, fvar, fmean_rt
+        return out
+    finally:
+        if own:
+            gp.close()
+
+
 def operational_forecast(script, SIC, SIEs_dt, SIEs_trend, ymax, SST=None, gp=None):
     """``forecast(ymax)`` of the operational scripts -> {region: dict(fmean, fvar, fmean_rt)} (unrounded)."""
     tab = SCRIPT_TABLE[script]

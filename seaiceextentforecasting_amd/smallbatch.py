@@ -10,6 +10,10 @@ Host side: data sets are staged in factored form so that the device never needs 
   expm="pade"  Sigma~ = scipy.linalg.expm(l M) per (data set, l) as the reference does (north/June1st.py:264), then
                Sigma~ = U diag(s) U^T;  A = [X ; Xs] U, weights s.  Reproduces the reference's numbers also for its
                extreme table entry l = 3.1e10, at one host eigendecomposition per (data set, l).
+
+``run(grad=True)`` is the MLII closure (north/June1st.py:235-257) for the whole list in the same single launch: the value, the
+reference's own "gradient" formulae (:248-252) and the exact derivative (``sigp_small_run_grad``).  M Sigma~ needs no second
+matrix: in the eigenbasis it is the reweighting lam_k exp(l lam_k); "pade" sets carry u_k^T M u_k * s_k instead.
 """
 import numpy as np
 
@@ -26,7 +30,7 @@ class SmallBatch:
         self.gp = gp
         self._data = []          # (X, y, Xs, M)
         self._eig = {}           # ds -> (lam, Q)
-        self._sets = []          # device sets: (A, y, lam, mode)
+        self._sets = []          # device sets: (A, y, lam, mode, dlam)
         self._set_of = {}        # (ds, None) or (ds, ell) -> device set index
         self._fits = []          # (device set, ell, sn)
         self._packed = None      # the fit list as arrays (rebuilt after add_fit)
@@ -66,13 +70,16 @@ class SmallBatch:
                 lam, Q = np.linalg.eigh(0.5 * (M + M.T))
                 self._eig[ds] = (np.minimum(lam, 0.0), Q)      # the exact spectrum is <= 0
             lam, Q = self._eig[ds]
-            dev = (np.ascontiguousarray(XX @ Q), y, np.ascontiguousarray(lam), 0)
+            dev = (np.ascontiguousarray(XX @ Q), y, np.ascontiguousarray(lam), 0, np.zeros_like(lam))
         else:
             Sig = sigma_tilde(M, float(ell))
             if not np.all(np.isfinite(Sig)):
                 raise FloatingPointError("expm(l M) overflowed")
             s, U = np.linalg.eigh(0.5 * (Sig + Sig.T))
-            dev = (np.ascontiguousarray(XX @ U), y, np.ascontiguousarray(s), 1)
+            # M and Sigma~ = expm(l M) share eigenvectors: M Sigma~ = U diag(mu s) U^T with mu_k = u_k^T M u_k (the MLII gradient's
+            # d Sigma/dl, north/June1st.py:248); inside a degenerate cluster of s the choice of U does not matter where s ~ 0
+            mu = np.einsum("ik,ij,jk->k", U, M, U)
+            dev = (np.ascontiguousarray(XX @ U), y, np.ascontiguousarray(s), 1, np.ascontiguousarray(mu * np.maximum(s, 0.0)))
         self._sets.append(dev)
         self._set_of[key] = len(self._sets) - 1
         return self._set_of[key]
@@ -106,11 +113,29 @@ class SmallBatch:
         gp = self.gp
         gp._check(gp._lib.sigp_small_upload(gp._h, len(sets), L.iptr(n), L.iptr(N), L.iptr(m), L.iptr(mode), L.ptr(A), L.iptr(a_off),
                                             L.ptr(y), L.iptr(y_off), L.ptr(lam), L.iptr(l_off)), "small_upload")
+        if mode.any():
+            dlam = np.concatenate([s[4] for s in sets])
+            gp._check(gp._lib.sigp_small_set_dweights(gp._h, L.ptr(dlam), len(dlam)), "small_set_dweights")
         self._uploaded = len(sets)
         self._mmax = int(m.max())
 
-    def run(self):
-        """All queued fits in one launch -> dict(sigma_f, nlml, info, sigma_n, mean [F, mmax], var [F, mmax])."""
+    def clear_fits(self):
+        """Forget the queued fits; the data sets (and what is staged in HBM) stay."""
+        self._fits = []
+        self._packed = None
+
+    def evaluate(self, ds, ell, sn_tilde, expm="eigh", grad=True):
+        """Replace the queue by fit i = data set ds[i] at (ell[i], sn_tilde[i]) and run it: what one round of a lockstep optimiser
+        over all (region, year) data sets asks for.  With expm="eigh" nothing but the 24 bytes per fit crosses the bus."""
+        self.clear_fits()
+        for d, e, s_ in zip(ds, ell, sn_tilde):
+            self.add_fit(int(d), e, s_, expm=expm)
+        return self.run(grad=grad)
+
+    def run(self, grad=False):
+        """All queued fits in one launch -> dict(sigma_f, nlml, info, sigma_n, mean [F, mmax], var [F, mmax]); with ``grad=True``
+        also grad_ref [F, 2] (the reference's MLII formulae, north/June1st.py:248-252) and grad_exact [F, 2] (the derivative of the
+        profiled nlML w.r.t. (log l, log sn~)); +inf where K~ is not positive definite (:254-256)."""
         if self._uploaded != len(self._sets):
             self.upload()
         F = len(self._fits)
@@ -119,9 +144,13 @@ class SmallBatch:
             self._packed = (np.ascontiguousarray(arr[:, 0], dtype=np.int64), np.ascontiguousarray(arr[:, 1]), np.ascontiguousarray(arr[:, 2]))
         si, ell, sn = self._packed
         ms = max(self._mmax, 1)
-        out = np.zeros((F, 4)); mean = np.full((F, ms), np.nan); var = np.full((F, ms), np.nan)
+        out = np.zeros((F, 8 if grad else 4)); mean = np.full((F, ms), np.nan); var = np.full((F, ms), np.nan)
         gp = self.gp
-        gp._check(gp._lib.sigp_small_run(gp._h, F, L.iptr(si), L.ptr(ell), L.ptr(sn), L.ptr(out), L.ptr(mean), L.ptr(var), ms), "small_run")
+        fn = gp._lib.sigp_small_run_grad if grad else gp._lib.sigp_small_run
+        gp._check(fn(gp._h, F, L.iptr(si), L.ptr(ell), L.ptr(sn), L.ptr(out), L.ptr(mean), L.ptr(var), ms), "small_run")
         gp._fitted = False
-        return dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
-                    mean=mean[:, :self._mmax], var=var[:, :self._mmax])
+        res = dict(sigma_f=out[:, 0], nlml=out[:, 1], info=out[:, 2].astype(np.int64), sigma_n=out[:, 3],
+                   mean=mean[:, :self._mmax], var=var[:, :self._mmax])
+        if grad:
+            res["grad_ref"], res["grad_exact"] = out[:, 4:6].copy(), out[:, 6:8].copy()
+        return res

@@ -1,0 +1,185 @@
+"""GPU tier, round 5: the reference's MLII closure (north/June1st.py:235-257) batched for the reference's OWN kernel -- value,
+the reference's "gradient" formulae and the exact derivative for every (data set, theta) of a list in ONE launch -- the lockstep
+optimiser over the retro loop's (region, year) data sets (the call the reference left commented out, :259-262), and the bench's
+own step shapes against the oracle.
+
+Tolerances as in test_hip_parity.py (predictions <= 1e-8 relative, nlML / sigma_f <= 1e-9) unless stated.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_NAMES, load_golden
+from oracle import gp_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def S():
+    import seaiceextentforecasting_amd as pkg
+    return pkg
+
+
+@pytest.fixture(scope="module")
+def all_records():
+    recs = []
+    for name in GOLDEN_NAMES:
+        for r in load_golden(name)["records"]:
+            recs.append((name, r))
+    return recs
+
+
+# ---- a9 batched: the reference's live closure, every golden record x every theta, ONE launch ---------------------------------
+@pytest.mark.parametrize("expm", ["eigh", "pade"])
+def test_mlii_closure_all_golden_records_in_one_launch(S, all_records, expm):
+    """63 (region, year) records x 6 theta of the reference's live ``MLII`` closure (captured by tests/golden/make_golden.py) through
+    ``sigp_small_run_grad``: one workgroup per (record, theta), one launch.  Value <= 1e-9; the reference's "gradient" (:248-252) to the
+    tolerance of test_mlii_contract_against_reference_closure (both sides carry cond(K~) eps: the reference sums
+    tr(solve(L.T, solve(L, dK))) in LU arithmetic); the except branch -> (inf, [inf, inf]) (:254-256)."""
+    assert len(all_records) == 63
+    with S.GPR(kernel="netdiffusion") as gp:
+        sb = S.SmallBatch(gp)
+        want = []
+        for _, r in all_records:
+            ds = sb.add_dataset(r["X"], r["y"], r["Xs"], r["M"])
+            for th, nl, gr in zip(r["mlii_theta"], r["mlii_nlml"], r["mlii_grad"]):
+                ell, sn = float(np.exp(th[0])), float(np.exp(th[1]))
+                if expm == "eigh" and ell > 1e6:
+                    continue          # l = 3.1e10: the eigen route and scipy's Pade expm differ beyond ~1e-10 there
+                sb.add_fit(ds, ell, sn, expm=expm)
+                want.append((r, th, nl, gr))
+        assert len(want) >= 63 * 5
+        gp.profile(True, ["small"])
+        launches0 = gp.profile_get()["small"]["launches"]
+        res = sb.run(grad=True)
+        assert gp.profile_get()["small"]["launches"] - launches0 == 1          # ONE launch for the lot
+    ninf = 0
+    for i, (r, th, nl, gr) in enumerate(want):
+        if np.isinf(nl):
+            ninf += 1
+            assert res["info"][i] > 0 and np.isinf(res["nlml"][i]) and np.all(np.isinf(res["grad_ref"][i])) and np.all(np.isinf(res["grad_exact"][i])), (i, th)
+            continue
+        assert res["info"][i] == 0
+        if np.exp(th[0]) > 1e6:
+            assert np.all(np.isfinite(res["grad_ref"][i]))
+            continue          # expm(l M) moves by ~1e-6 under 1-ulp changes of l there: as in the single-fit test
+        assert abs(res["nlml"][i] - nl) <= 1e-9 * abs(nl), (i, th, res["nlml"][i], nl)
+        Kt = O.fit_predict(r["X"], r["y"], r["Xs"], float(np.exp(th[0])), float(np.exp(th[1])), M=r["M"], ref_idiom=False)["K_tilde"]
+        tol = max(1e-7, 1e3 * 2.3e-16 * np.linalg.cond(Kt))
+        assert np.max(np.abs(res["grad_ref"][i] - gr)) <= tol * max(1.0, np.max(np.abs(gr))), (i, th, res["grad_ref"][i], gr)
+    assert ninf == 63           # every record carries one theta of the except branch
+
+
+def test_batched_exact_gradient_matches_oracle_and_single_fit_path(S, all_records):
+    """grad_exact of the batched kernel == O.mlii(grad='exact') == the blocked engine's single-fit gp.nlml(grad='exact'), on golden
+    records and on ragged synthetic sets up to n = 128 (N > n and N < n, ch-chunked features)."""
+    rng = np.random.default_rng(21)
+    sets = [(r["X"], r["y"][:, 0], r["M"]) for _, r in all_records[::9]]
+    for n, N in ((128, 60), (100, 130), (45, 200), (2, 1), (7, 3), (64, 33)):
+        X = rng.standard_normal((n, N)); y = X @ rng.standard_normal(N) / np.sqrt(N) + 0.3 * rng.standard_normal(n)
+        sets.append((X, y, None))
+    thetas = [np.array([np.log(0.14), np.log(6.1)]), np.array([np.log(1.8e-3), np.log(0.33)]), np.array([np.log(0.02), np.log(0.05)])]
+    with S.GPR(kernel="netdiffusion") as gp:
+        gp.upload_batch([s[0] for s in sets], [s[1] for s in sets], None, M=[s[2] for s in sets])
+        B = len(sets)
+        th = np.array([t for t in thetas for _ in range(B)])                     # pair i -> data set i % B
+        val, g = gp.nlml_batch(th, grad="exact")
+        val_r, g_r = gp.nlml_batch(th, grad="ref")
+        val_p, g_p = gp.nlml_batch(th, grad="exact", expm="pade")
+        assert np.array_equal(val, val_r)
+    for i in range(len(th)):
+        X, y, M = sets[i % B]
+        fo, go = O.mlii(th[i], X, y, M=M, grad="exact")
+        fr, gr = O.mlii(th[i], X, y, M=M, grad="ref")
+        Kt = O.fit_predict(X, y, np.zeros((1, X.shape[1])), float(np.exp(th[i][0])), float(np.exp(th[i][1])), M=M, ref_idiom=False)["K_tilde"]
+        tol = max(1e-7, 1e3 * 2.3e-16 * np.linalg.cond(Kt))
+        assert abs(val[i] - fo) <= 1e-9 * abs(fo), (i, X.shape)
+        assert np.max(np.abs(g[i] - go)) <= tol * max(1.0, np.max(np.abs(go))), (i, X.shape, g[i], go)
+        assert np.max(np.abs(g_r[i] - gr)) <= tol * max(1.0, np.max(np.abs(gr))), (i, X.shape, g_r[i], gr)
+        assert abs(val_p[i] - fo) <= 1e-9 * abs(fo) and np.max(np.abs(g_p[i] - go)) <= tol * max(1.0, np.max(np.abs(go))), (i, X.shape, g_p[i], go)
+    X, y, M = sets[0]
+    with S.GPR(kernel="netdiffusion") as gp:                                   # the single-fit path of the blocked engine
+        gp.set_data(X, y, M=M)
+        f1, g1 = gp.nlml(thetas[0], grad="exact")
+    assert abs(f1 - val[0]) <= 1e-9 * abs(f1) and np.allclose(g1, g[0], rtol=1e-7, atol=1e-8)
+    # finite differences of the batched value itself
+    with S.GPR(kernel="netdiffusion") as gp:
+        gp.upload_batch([X], [y], None, M=[M])
+        h = 1e-5
+        pts = np.array([thetas[0] + h * e for e in np.eye(2)] + [thetas[0] - h * e for e in np.eye(2)])
+        v, _ = gp.nlml_batch(pts, grad=None)
+        fd = (v[:2] - v[2:]) / (2 * h)
+    assert np.allclose(g[0], fd, rtol=1e-5, atol=1e-6), (g[0], fd)
+
+
+def test_batched_mlii_overflow_and_bad_arguments(S):
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((30, 5)); y = rng.standard_normal(30)
+    with S.GPR(kernel="netdiffusion") as gp:
+        with pytest.raises(RuntimeError):
+            gp.nlml_batch(np.zeros((1, 2)))
+        gp.upload_batch([X], [y], None)
+        v, g = gp.nlml_batch(np.array([[800.0, 0.0], [0.0, 800.0], [np.log(0.1), 0.0]]), grad="ref")     # exp overflows: :254-256
+        assert np.isinf(v[0]) and np.isinf(v[1]) and np.all(np.isinf(g[:2])) and np.isfinite(v[2]) and np.all(np.isfinite(g[2]))
+        with pytest.raises(ValueError):
+            gp.nlml_batch(np.zeros((1, 2)), grad="both")
+        with pytest.raises(ValueError):
+            gp.nlml_batch(np.zeros((1, 3)))
+    with S.GPR(kernel="rbf") as gp:
+        with pytest.raises(ValueError):
+            gp.nlml_batch(np.zeros((1, 2)), grad="ref")
+
+
+# ---- f1: the reference's optimiser call for its own kernel, every (region, year) of a retro run in lockstep ---------------------
+@pytest.mark.parametrize("script", ["north_September", "south_January", "north_June"])
+def test_retro_optimiser_lockstep_reaches_the_single_fit_stationary_points(S, script):
+    """``retro_optimise``: the 3 regions x years optimisers of a retro run (September1st_retro.py:176-180 with :259-262 re-enabled)
+    advance together, one launch per round; <= 40 device calls; every data set ends at a stationary point of ITS nlML (checked with the
+    oracle's exact gradient), at or below the value scipy's L-BFGS-B reaches from the same x0 on the single-fit path of the blocked
+    engine (``GPR.optimize``), and the same driver run ONE data set at a time through ``GPR.nlml`` lands on the same point."""
+    from seaiceextentforecasting_amd.optim import newton_lockstep
+    from seaiceextentforecasting_amd.retro import _problem, _retro_inputs
+    g = load_golden(script + "_retro")
+    fmin, fmax = g["args"]
+    out = S.retro_optimise(script, g["SIC"], g["SIEs_dt"], fmin, fmax, SST=g["SST"], SIEs_trend=g["SIEs_trend"], maxiter=40)
+    assert out["nfev"] <= 40, out["nfev"]
+    tab = S.SCRIPT_TABLE[script]
+    checked = 0
+    for k, region in enumerate(tab["regions"]):
+        r = out[region]
+        assert np.all(r["converged"]), (region, r)
+        assert out[region + "_fmean"].shape == (fmax - fmin + 1,) and np.all(np.isfinite(out[region + "_fvar"]))
+        for year in range(fmin, fmax + 1):
+            i = year - fmin
+            _, y, sic, sst = _retro_inputs(tab, g["SIC"], g["SIEs_dt"], g["SST"], region, year, fmin)
+            X, Xs, M = _problem(tab, k, y, sic, sst)
+            fo, go = O.mlii(r["x"][i], X, y, M=M, grad="exact")
+            assert abs(fo - r["fun"][i]) <= 1e-8 * max(1.0, abs(fo))
+            assert np.max(np.abs(go)) <= 1e-3 * max(1.0, abs(fo)), (region, year, go)         # stationary for the oracle too
+            x0 = np.array([np.log(tab["ell"][k]), np.log(tab["sn"][k])])
+            with S.GPR(kernel="netdiffusion", expm="eigh") as gp:
+                gp.set_data(X, y, M=M)
+                single = gp.optimize(x0)                                                       # scipy L-BFGS-B, blocked engine
+                assert r["fun"][i] <= single.fun + 1e-6 * max(1.0, abs(single.fun)), (region, year, r["fun"][i], single.fun)
+
+                def one(th, own):
+                    vals = [gp.nlml(t, grad="exact") for t in th]
+                    return np.array([v for v, _ in vals]), np.array([gg for _, gg in vals])
+
+                alone = newton_lockstep(one, x0[None], maxiter=40, ftol=1e-12)
+            assert abs(alone["fun"][0] - r["fun"][i]) <= 1e-7 * max(1.0, abs(r["fun"][i])), (region, year, alone["fun"], r["fun"][i])
+            assert np.max(np.abs(alone["x"][0] - r["x"][i])) <= 1e-3, (region, year, alone["x"], r["x"][i])
+            checked += 1
+    assert checked == 3 * (fmax - fmin + 1)
