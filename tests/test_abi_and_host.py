@@ -502,6 +502,7 @@ def test_lockstep_optimiser_drivers_on_the_oracle():
     from seaiceextentforecasting_amd.optim import bfgs_lockstep, newton_lockstep
     from seaiceextentforecasting_amd.retro import _problem, _retro_inputs
     from seaiceextentforecasting_amd.features import SCRIPT_TABLE
+    from conftest import load_golden
     g = load_golden("north_June_retro")
     fmin, fmax = g["args"]
     tab = SCRIPT_TABLE["north_June"]
