@@ -185,3 +185,85 @@ def test_retro_optimiser_lockstep_reaches_the_single_fit_stationary_points(S, sc
             assert np.max(np.abs(O.mlii(alone["x"][0], X, y, M=M, grad="exact")[1])) <= 1e-3 * max(1.0, abs(fo))
             checked += 1
     assert checked == 3 * (fmax - fmin + 1)
+
+
+# ---- what the driver times: the bench's own step shapes ----------------------------------------------------------------------------
+TOL_PRED = 1e-8
+
+
+def _bench_years(n, d, years):
+    import bench
+    Xb = np.zeros((years, n, d)); yb = np.zeros((years, n)); Xsb = np.zeros((years, 1, d))
+    for b in range(years):
+        Xb[b], yb[b], Xsb[b] = bench.synthetic_problem(n, d, 20240002 + b, m=1)
+    return Xb, yb, Xsb
+
+
+@pytest.mark.timeout(1200)
+def test_bench_configuration_lockstep_g160_against_oracle(S):
+    """configs[2] exactly as the default ``python bench.py`` times it: ONE lockstep step of G = 160 members -- the 40 years at 4 consecutive
+    grid points of ``bench.grid_point`` (the first timed step: points 4 .. 7 after one warm-up step), n = 8192, d = 8, W = 8.  One member per
+    grid point against the oracle; ALL 160 members against the same fits factorised in the lockstep groups of 40 that
+    test_bench_configuration_lockstep_g40_against_oracle pins (the group size is a schedule: same tile kernels, same k order)."""
+    import bench
+    n, d, years, G = 8192, 8, 40, 160
+    Xb, yb, Xsb = _bench_years(n, d, years)
+    fits = np.arange(G, 2 * G)                                   # the first timed step of the default run (warmup = 1)
+    pts = [bench.grid_point(int(i // years), d, "smoke") for i in fits]
+    ell = np.array([p[0] for p in pts]); sn = np.array([p[1] for p in pts])
+    assert len({p for p in pts}) == 4
+    with S.GPR(kernel="rbf", outer_blocks=8) as gp:
+        gp.upload_batch(Xb, yb, Xsb, group=G, concurrency=1)
+        r = gp.run_batch(G, G, ell, sn, concurrency=1, group=G)            # fit i uses data set i % 40, as in the bench
+        r40 = [gp.run_batch(G + 40 * q, 40, ell[40 * q:40 * q + 40], sn[40 * q:40 * q + 40], concurrency=1, group=40) for q in range(4)]
+    assert np.all(r["info"] == 0) and np.all(r["var"] > 0) and np.all(np.isfinite(r["nlml"])) and np.all(np.isfinite(r["mean"]))
+    for q in range(4):
+        for key in ("mean", "var", "nlml", "sigma_f"):
+            a, b = np.asarray(r[key][40 * q:40 * q + 40]), np.asarray(r40[q][key])
+            assert np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) <= 1e-12, (q, key)
+    for i in (0, 53, 106, 159):                                  # one member per grid point
+        b = int(fits[i] % years)
+        ref = O.fit_predict(Xb[b], yb[b], Xsb[b], ell[i], sn[i], kind="rbf", ref_idiom=False)
+        assert rel(r["mean"][i], ref["fmean"]) <= TOL_PRED and rel(r["var"][i], ref["fvar"]) <= TOL_PRED, i
+        assert rel(r["nlml"][i], ref["nlml"]) <= 1e-9 and rel(r["sigma_f"][i], ref["sigma_f"]) <= 1e-9, i
+
+
+@pytest.mark.timeout(1200)
+def test_bench_full_grid_every_point_at_n8192(S):
+    """``--grid full``: all 400 points of l = sqrt(d) logspace(-1, 1, 20) x sn~ = logspace(-3, 1, 20) at n = 8192 (4 years per point, 40 points
+    per lockstep launch of 160): every fit succeeds with finite results, and the four corners of the grid (the extremes of both ranges) agree
+    with the oracle.  cond(K~) reaches ~ n / sn~ = 8e6 at the small-noise corners: predictions stay within 1e-8 of the oracle's."""
+    import bench
+    n, d, years, G = 8192, 8, 4, 160
+    Xb, yb, Xsb = _bench_years(n, d, years)
+    F = 400 * years
+    pts = [bench.grid_point(int(i // years), d, "full") for i in range(F)]
+    ell = np.array([p[0] for p in pts]); sn = np.array([p[1] for p in pts])
+    assert len(set(pts)) == 400
+    with S.GPR(kernel="rbf", outer_blocks=8) as gp:
+        gp.upload_batch(Xb, yb, Xsb, group=G, concurrency=1)
+        r = gp.run_batch(0, F, ell, sn, concurrency=1, group=G)
+    assert np.all(r["info"] == 0), np.flatnonzero(r["info"])[:10]
+    assert np.all(np.isfinite(r["mean"])) and np.all(np.isfinite(r["nlml"])) and np.all(np.isfinite(r["sigma_f"])) and np.all(r["var"] > 0)
+    ells, sns = bench.grid_axes(d, "full")
+    for e, s_ in ((ells[0], sns[0]), (ells[-1], sns[0]), (ells[0], sns[-1]), (ells[-1], sns[-1])):
+        i = int(np.flatnonzero((ell == e) & (sn == s_))[0])
+        b = i % years
+        ref = O.fit_predict(Xb[b], yb[b], Xsb[b], e, s_, kind="rbf", ref_idiom=False)
+        scale = max(np.max(np.abs(ref["fmean"])), np.max(np.abs(ref["KXXs"])) * np.max(np.abs(ref["alpha"])))
+        assert np.max(np.abs(r["mean"][i] - ref["fmean"])) <= TOL_PRED * scale, (e, s_, r["mean"][i], ref["fmean"])
+        assert np.max(np.abs(r["var"][i] - ref["fvar"])) <= TOL_PRED * np.max(np.abs(ref["kss"])), (e, s_, r["var"][i], ref["fvar"])
+        assert rel(r["nlml"][i], ref["nlml"]) <= 1e-9 and rel(r["sigma_f"][i], ref["sigma_f"]) <= 1e-8, (e, s_)
+
+
+def test_bench_falls_back_to_fewer_grid_points_when_hbm_is_short():
+    """bench.py's memory fallback: with less free HBM than the group of 160 needs (SIGP_BENCH_FREE_BYTES overrides hipMemGetInfo) the step
+    shrinks by WHOLE years-worth of fits (160 -> 80 at 60 GB with no extras) and the compact line the driver parses shows both numbers."""
+    env = dict(os.environ, SIGP_BENCH_FREE_BYTES="60e9")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras", "--no-profile"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads(p.stdout.strip().splitlines()[-1])
+    assert line["config"]["fits_per_step"] == 80 and line["config"]["lockstep_group_asked"] == 160, line["config"]
+    assert line["value"] > 0 and line["steps"] == 1 and abs(line["value"] - 80 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
+    assert len(p.stdout.strip().splitlines()[-1]) <= 1500
