@@ -113,6 +113,15 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
                 assert np.array_equal(mu3, mu2[3:4]) and np.array_equal(var3, var2[3:4])
             dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
             assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
+            # a bad hyper-parameter (an optimiser proposing l <= 0 / sn~ < 0) is an argument error on every rank alike, raised before any
+            # collective is entered: the sharded handle stays usable (ADVICE r4: it used to take the dead-communicator exit)
+            try:
+                dg.refit(*((-1.0, sn) if kind != "netdiffusion" else (ell, -1.0)))
+                raise SystemExit("expected ValueError")
+            except ValueError:
+                pass
+            dg.refit(ell, sn)
+            assert rel(dg.nlml_, O.fit_predict(X, 2.0 * y, Xs, ell, sn, kind=kind, ref_idiom=False)["nlml"]) <= 1e-9
     assert np.array_equal(bits[0][0], bits[1][0]) and np.array_equal(bits[0][1], bits[1][1]) and bits[0][2] == bits[1][2], "look-ahead changed the bits"
     # the panel exchange by ROW PIECES (dist_panel_split): top block broadcast, the rows below scattered / solved where they land / all-gathered.
     # Rows are independent: the same bits, with and without look-ahead; later predictions at new points read the factor in the owners' storage

@@ -15,7 +15,7 @@ def main():
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    import bench
+    import bench_extras
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")
@@ -23,7 +23,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local)) if backend == "nccl" else dist.init_process_group(backend)
         d = dist
-    rec = bench.sharded_record(rank, world, local, d, backend, configs=tuple(args.configs.split(",")), reps=args.reps, outer=args.outer)
+    rec = bench_extras.sharded_record(rank, world, local, d, backend, configs=tuple(args.configs.split(",")), reps=args.reps, outer=args.outer)
     if rank == 0:
         print(json.dumps(rec))
     if d is not None:
