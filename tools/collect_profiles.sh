@@ -5,7 +5,7 @@
 #   tools/collect_profiles.sh r03 pmc       PMC passes of the bench command (trailing update, covariance build)
 #   tools/collect_profiles.sh r03 f32       kernel stats + PMC passes of one fp32 fit at configs[4]'s shape (syrk128_kernel<float>)
 # then, back in the authoring container:  python tools/summarize_pmc.py r03
-R=${1:-r04}
+R=${1:-r05}
 WHAT=${2:-bench}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$R
 mkdir -p $OUT
@@ -24,6 +24,9 @@ if [ "$WHAT" = "pmc" ]; then
   done
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --no-profile > $OUT/pmc_mfma.json 2> $OUT/pmc_mfma.err || echo "mfma pmc pass failed"
   echo "pmc mfma done"
+  # LDS bank conflicts and occupancy (the chain kernels: diag_update, panel_strip, chain_link)
+  rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_lds -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --no-profile > $OUT/pmc_lds.json 2> $OUT/pmc_lds.err || echo "lds pmc pass failed"
+  echo "pmc lds done"
 fi
 if [ "$WHAT" = "f32" ]; then
   F32="python3 $GRAFT_REPO_ROOT/tools/shard_profile.py --single --dtype f32 --n 32768 --d 32 --kernel matern52 --sn 0.1 --reps 2"

@@ -1,14 +1,18 @@
 #!/bin/bash
 # Per-path kernel-trace summaries (tools/trace_summary.py) of the current build: batch group, single fits n = 4096 / 16384 (fp64), fp32 n = 32768.
 # Runs on the GPU box; outputs gpurun_out/<round>_traces/*.txt (copy the ones to be judged into profiles/).
-R=${1:-r04}
+R=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${R}_traces
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 run() {  # name, program args...
   local name=$1; shift
   rocprofv3 --kernel-trace --output-format csv -d $OUT/$name -o t -- python3 "$@" > $OUT/$name.log 2>&1 || return 1
-  python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $(find $OUT/$name -name "*kernel_trace.csv" | head -1) > $OUT/${R}_trace_$name.txt 2>&1
+  if [ "$name" = "batch_group" ]; then
+    python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $(find $OUT/$name -name "*kernel_trace.csv" | head -1) kbuild --critical-path $OUT/${R}_critical_path.json > $OUT/${R}_trace_$name.txt 2>&1
+  else
+    python3 $GRAFT_REPO_ROOT/tools/trace_summary.py $(find $OUT/$name -name "*kernel_trace.csv" | head -1) > $OUT/${R}_trace_$name.txt 2>&1
+  fi
   rm -rf $OUT/$name
   echo "$name done"
 }

@@ -3,7 +3,7 @@ import json, os, sys
 import pandas as pd
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 base = "gpurun_out/%s/" % rnd
 out = {"command": "rocprofv3 --pmc <C> --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --steps 1 --warmup 1 --no-profile  (one pass per counter set; default lockstep group)",
        "kernel": "sigp::syrk128_kernel<double, false, false>", "notes": [],
@@ -49,6 +49,46 @@ kb["hbm_total_GBps"] = (kb["write_bytes_per_launch"] + kb["fetch_bytes_per_launc
 kb["frac_of_8TBps"] = kb["hbm_total_GBps"] / 8000.0
 json.dump(kb, open("profiles/%s_pmc_kbuild.json" % rnd, "w"), indent=1)
 print("kbuild: write GB %.2f fetch GB %.2f in %.3f ms -> %.2f TB/s" % (kb["write_bytes_per_launch"] / 1e9, kb["fetch_bytes_per_launch_corrected"] / 1e9, kb["rocprofv3_stats_avg_ms"], kb["hbm_total_GBps"] / 1e3))
+
+# the chain kernels of the same bench command: what the panel stream's launches do with the chip while the trailing update shares it
+try:
+    fe_all = pd.read_csv(base + "pmc_FETCH_SIZE/bench_counter_collection.csv"); wr_all = pd.read_csv(base + "pmc_WRITE_SIZE/bench_counter_collection.csv")
+    mf_all = pd.read_csv(base + "pmc_mfma/bench_counter_collection.csv")
+    st_all = pd.read_csv(base + "stats/bench_kernel_stats.csv")
+    try:
+        lds_all = pd.read_csv(base + "pmc_lds/bench_counter_collection.csv")
+    except Exception:
+        lds_all = None
+    chain = {"command": out["command"], "lockstep_group": G, "kernel_code_sha16": out["kernel_code_sha16"], "kernels": {},
+             "notes": ["per launch, averaged over the launches of one bench command (PMC collection serialises kernels: these are the kernels ALONE on the chip, not beside the trailing update)",
+                       "flops from the engine's own accounting are not in the PMC passes; mfma_pipe_busy_fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+                       "lds_bank_conflict_fraction = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (cycles); waves_per_launch = SQ_WAVES"]}
+    for key in ("diag_update_kernel<double", "panel_strip_kernel<double", "chain_link_kernel<double", "potrf_diag_kernel<double", "syrk128_kernel<double, true"):
+        sel2 = lambda df, col: df[df[col].str.contains(key, regex=False)]
+        fk2, wk2, mk2, sk2 = sel2(fe_all, "Kernel_Name"), sel2(wr_all, "Kernel_Name"), sel2(mf_all, "Kernel_Name"), sel2(st_all, "Name")
+        if not len(fk2) or not len(sk2):
+            continue
+        gm = mk2.groupby("Counter_Name")["Counter_Value"].sum()
+        e = {"launches_pmc": int(len(fk2)), "rocprofv3_stats_calls": int(sk2["Calls"].iloc[0]), "rocprofv3_stats_avg_ms": float(sk2["AverageNs"].iloc[0]) / 1e6,
+             "rocprofv3_stats_total_ms": float(sk2["TotalDurationNs"].iloc[0]) / 1e6,
+             "fetch_bytes_per_launch_corrected": float(fk2["Counter_Value"].mean()) * 1024 * 2, "write_bytes_per_launch": float(wk2["Counter_Value"].mean()) * 1024,
+             "mfma_pipe_busy_fraction": float(gm["SQ_VALU_MFMA_BUSY_CYCLES"] / (gm["GRBM_GUI_ACTIVE"] / 8 * 1024)) if "GRBM_GUI_ACTIVE" in gm and gm["GRBM_GUI_ACTIVE"] > 0 else None}
+        if "SQ_BUSY_CU_CYCLES" in gm and "GRBM_GUI_ACTIVE" in gm and gm["GRBM_GUI_ACTIVE"] > 0:
+            e["cu_busy_fraction"] = float(gm["SQ_BUSY_CU_CYCLES"] / (gm["GRBM_GUI_ACTIVE"] / 8 * 256))
+        if lds_all is not None:
+            gl = sel2(lds_all, "Kernel_Name").groupby("Counter_Name")["Counter_Value"].sum()
+            if "SQ_LDS_BANK_CONFLICT" in gl and "SQ_LDS_IDX_ACTIVE" in gl and gl["SQ_LDS_IDX_ACTIVE"] > 0:
+                e["lds_bank_conflict_fraction"] = float(gl["SQ_LDS_BANK_CONFLICT"] / gl["SQ_LDS_IDX_ACTIVE"])
+            lw = sel2(lds_all, "Kernel_Name")
+            lw = lw[lw["Counter_Name"] == "SQ_WAVES"]
+            if len(lw):
+                e["waves_per_launch"] = float(lw["Counter_Value"].mean())
+        e["hbm_total_GBps_alone"] = (e["fetch_bytes_per_launch_corrected"] + e["write_bytes_per_launch"]) / (e["rocprofv3_stats_avg_ms"] * 1e-3) / 1e9
+        chain["kernels"][key] = e
+    json.dump(chain, open("profiles/%s_pmc_chain_kernels.json" % rnd, "w"), indent=1)
+    print("chain kernels:", {k: (round(v["rocprofv3_stats_avg_ms"], 3), v["mfma_pipe_busy_fraction"]) for k, v in chain["kernels"].items()})
+except FileNotFoundError as e:
+    print("no chain-kernel passes:", e)
 
 # the fp32 trailing update at configs[4]'s shape (one fit, n = 32768, d = 32): tools/collect_profiles.sh <round> f32
 try:
