@@ -40,12 +40,40 @@ __device__ __forceinline__ double exp_cov(double x) {
   return ldexp(p, (int)k);
 }
 
+// The same function with 6 of the argument reduction's bits moved into a 64-entry table of 2^(j/64) (in LDS: one ds_read_b64 per call on the
+// LDS port, which the build leaves idle): k = rint(64 x log2 e), r = x - k ln2 / 64 (|r| <= 0.0054), degree-5 polynomial (truncation 4e-17),
+// exp(x) = 2^(k >> 6) tab[k & 63] p(r).  16 VALU instructions instead of 21: the covariance build is VALU-bound beside its stores.  The
+// table is filled by exp_cov itself (exp_tab_fill, 64 threads, once per workgroup): <= 4 ulp in all.
+__device__ __forceinline__ void exp_tab_fill(double* tab, int tid) {
+  if (tid < 64) tab[tid] = exp_cov(-(double)((64 - tid) & 63) * (6.93147180559945286227e-01 / 64.0)) * (tid ? 2.0 : 1.0);   // 2^(tid/64) = 2 exp(-(64 - tid) ln2 / 64)
+}
+__device__ __forceinline__ double exp_cov_tab(double x, const double* tab) {
+  x = fmax(x, -746.0);
+  const double k = __builtin_rint(x * (64.0 * 1.44269504088896338700e+00));
+  double r = fma(-k, kExpCoef.ln2hi * (1.0 / 64.0), x);
+  r = fma(-k, kExpCoef.ln2lo * (1.0 / 64.0), r);
+  const int ki = (int)k;
+  const double t = tab[ki & 63];
+  double p = kExpCoef.c[5];
+#pragma unroll
+  for (int i = 4; i >= 0; --i) p = fma(p, r, kExpCoef.c[i]);
+  return ldexp(t * p, ki >> 6);
+}
+
 __device__ inline double cov_from_sq(const KParams& kp, double sq) {
   if (kp.kernel_id == KID_RBF) return exp_cov(kp.c_rbf * sq);
   if (kp.kernel_id == KID_RBF_DLOGL) return exp_cov(kp.c_rbf * sq) * sq * (kp.inv_ell * kp.inv_ell);   // k * |d|^2 / l^2
   const double s = sqrt(5.0 * sq) * kp.inv_ell;
   if (kp.kernel_id == KID_MATERN52_DLOGL) return (s * s * (1.0 / 3.0)) * (1.0 + s) * exp_cov(-s);
   return (1.0 + s + s * s * (1.0 / 3.0)) * exp_cov(-s);
+}
+__device__ inline double cov_from_sq_tab(const KParams& kp, double sq, const double* tab) {      // (the two covariance functions of a fit, table-driven exp)
+  if (kp.kernel_id == KID_RBF) return exp_cov_tab(kp.c_rbf * sq, tab);
+  if (kp.kernel_id == KID_MATERN52) {
+    const double s = sqrt(5.0 * sq) * kp.inv_ell;
+    return (1.0 + s + s * s * (1.0 / 3.0)) * exp_cov_tab(-s, tab);
+  }
+  return cov_from_sq(kp, sq);
 }
 
 // K5 (north/June1st.py:265 with an RBF / Matern-5/2 covariance in place of X Sigma X^T):
@@ -96,7 +124,9 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
   Mat += blockIdx.z * strideM;
   __shared__ double Xi[KB_TM][DC + 1];                                    // DC = 8 for d <= 8: 12 KB instead of 50 KB of LDS, so the
   __shared__ __attribute__((aligned(16))) double XjT[DC][KB_TN + 2];      // CU holds enough workgroups to overlap one's exp() with another's stores
+  __shared__ double etab[64];                                             // 2^(j/64) for exp_cov_tab (published by the staging loop's barriers)
   const int tid = threadIdx.x;
+  exp_tab_fill(etab, tid);
   const int c4 = (tid & 31) * 4, rg = tid >> 5;
   double acc[8][4];
 #pragma unroll
@@ -131,17 +161,29 @@ __global__ __launch_bounds__(256) void kbuild_kernel(const double* __restrict__ 
       }
     }
   }
+  // Tiles that neither touch the diagonal nor the padding (all but 2 T of the T (T + 1) tiles of a member) take a path without the per-element
+  // index compares and selects: the build is VALU-bound beside its stores (tools/kbuild_bench.py), and those were ~6 of ~46 instructions
+  // per element.  Same values.
+  const bool interior = bi * KB_TM + KB_TM <= n && bj * KB_TN + KB_TN <= n && (bi * KB_TM + KB_TM <= bj * KB_TN || bi * KB_TM >= bj * KB_TN + KB_TN);
 #pragma unroll
   for (int s = 0; s < 8; ++s) {
     const int gi = bi * KB_TM + rg + 8 * s, gj = bj * KB_TN + c4;
     KbOut4<TO> o;
     KbOut4<double> o64;
+    if (interior) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      double v;
-      if (gi >= n) v = (gi == gj + c && !full) ? 1.0 : 0.0;
-      else v = (gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq(kp, acc[s][c])) + (gi == gj + c ? kp.sn : 0.0) : 0.0;
-      o.v[c] = (TO)v; o64.v[c] = v;
+      for (int c = 0; c < 4; ++c) {
+        const double v = (flags & 2) ? acc[s][c] : cov_from_sq_tab(kp, acc[s][c], etab);
+        o.v[c] = (TO)v; o64.v[c] = v;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        double v;
+        if (gi >= n) v = (gi == gj + c && !full) ? 1.0 : 0.0;
+        else v = (gj + c < n) ? ((flags & 2) ? acc[s][c] : cov_from_sq_tab(kp, acc[s][c], etab)) + (gi == gj + c ? kp.sn : 0.0) : 0.0;
+        o.v[c] = (TO)v; o64.v[c] = v;
+      }
     }
     if (!(flags & 4) || o.v[0] == (TO)12345.678) *(KbOut4<TO>*)(Mat + (long)gi * ld + (mcol >= 0 ? mcol + c4 : (long)gj)) = o;
     // the same tile in fp64 beside a lower-precision one (fp32 engine: what the refinement's residuals read), same [row][ld] layout

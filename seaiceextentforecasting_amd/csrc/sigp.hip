@@ -186,6 +186,7 @@ struct sigp_handle {
   int opt_strip_min = 512;
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
+  int ncu = 256;              // compute units of the device
   int opt_kbuild_mfma = 2;   // covariance build: squared distances in GEMM form on the matrix pipe (kbuild_mfma_kernel): 2 = from 16 features on (below, the 2 d
                              // VALU instructions per element are not what the build waits for: same time either way), 1 = always, 0 = never (VALU)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
@@ -1218,6 +1219,7 @@ int sigp_create(sigp_handle** out, int device_id, int dtype) {
   sigp_handle* h = new sigp_handle();
   h->device = device_id;
   h->dtype = dtype;
+  if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device_id) != hipSuccess || h->ncu < 1) h->ncu = 256;
   int rc = slot_init(h, h->slots[0]);
   if (rc) { delete h; return rc; }
   h->nslots = 1;
