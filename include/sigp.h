@@ -251,6 +251,10 @@ typedef struct sigp_transport {
 int sigp_dist_unique_id(void* id128);
 int sigp_dist_init(sigp_handle* h, int nranks, int rank, const void* nccl_id);
 int sigp_dist_init_transport(sigp_handle* h, int nranks, int rank, const sigp_transport* transport);
+/* The same for a caller compiled against ANOTHER version of this header: struct_bytes = sizeof(sigp_transport) as the caller knows it; members
+ * beyond it read as NULL (the struct grew from four to six members in 4.0: a 3.x caller passes its shorter struct here, or sets scatter /
+ * allgather to NULL).  sigp_version() >= 500 has this entry point. */
+int sigp_dist_init_transport2(sigp_handle* h, int nranks, int rank, const sigp_transport* tr, int64_t struct_bytes);
 int sigp_dist_fit(sigp_handle* h, int kernel_id, double ell, double sn_tilde, const double* Sigma, int64_t ldsigma, int64_t W, int lookahead,
                   double* out, double* mean, double* var);
 /* Predictions at NEW test points after a sharded fit (north/June1st.py:272-277): collective -- every rank calls it with the same Xs [m,d]

@@ -58,6 +58,7 @@ SIGNATURES = {
     "sigp_dist_unique_id": (C.c_int, [C.c_void_p]),
     "sigp_dist_init": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
     "sigp_dist_init_transport": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p]),
+    "sigp_dist_init_transport2": (C.c_int, [_h, C.c_int, C.c_int, C.c_void_p, _i64]),
     "sigp_dist_fit": (C.c_int, [_h, C.c_int, C.c_double, C.c_double, _dp, _i64, _i64, C.c_int, _dp, _dp, _dp]),
     "sigp_dist_predict": (C.c_int, [_h, _dp, _i64, _i64, _dp, _dp]),
     "sigp_dist_shutdown": (C.c_int, [_h]),

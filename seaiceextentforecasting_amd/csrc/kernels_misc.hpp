@@ -1087,14 +1087,17 @@ __global__ __launch_bounds__(1024) void refine_norms_kernel(const double* __rest
   __shared__ double sh[16];
   const int b = blockIdx.x;
   const double* src = b < nrhs ? R + (long)b * ldr : y;
+  // max |.| that PROPAGATES NaN (fmax drops it): a non-finite residual -- a member whose factor was poisoned by a failed pivot -- must fail
+  // the refinement's stopping test and show up in refine_resid, not read as 0
+  auto nmax = [](double a, double v) { return (v != v || a != a) ? __builtin_nan("") : fmax(a, v); };
   double m = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) m = fmax(m, fabs(src[i]));
+  for (int i = threadIdx.x; i < n; i += 1024) m = nmax(m, fabs(src[i]));
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+  for (int off = 32; off > 0; off >>= 1) m = nmax(m, __shfl_xor(m, off, 64));
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 16; ++k) m = fmax(m, sh[k]);
+    for (int k = 1; k < 16; ++k) m = nmax(m, sh[k]);
     out[b] = m;
   }
 }

@@ -139,6 +139,7 @@ struct sigp_handle {
     void* tbuf[2] = {nullptr, nullptr}; size_t cap_tbuf = 0;   // row-split exchange: a panel's top block [W 128][W 128] + its W inverse diagonal blocks, in rotation
     hipEvent_t ev_solve[2] = {nullptr, nullptr};               // ... this rank's row piece of the panel is solved (the all-gather waits for it)
     hipEvent_t ev_seg = nullptr;                               // a segment has arrived (next owner's panel stream waits for it)
+    hipEvent_t ev_hot[2] = {nullptr, nullptr};                 // row-split exchange with the row-distributed first update: the panel's first rows below its top block have arrived, solved
     hipEvent_t ev_pack[2] = {nullptr, nullptr}, ev_bcast[2] = {nullptr, nullptr}, ev_read[2] = {nullptr, nullptr}, ev_first[2] = {nullptr, nullptr}, ev_mark = nullptr;
     std::vector<hipEvent_t> ev_t;              // timing events of the last fit (dist_stats)
     // sharded triangular solves of the fp32 refinement: inverses of the own panels' diagonal blocks, panel-major work vectors
@@ -160,7 +161,8 @@ struct sigp_handle {
     double st_link_bytes = 0, st_owner_ms = 0, st_split_panels = 0, st_link_panel_max = 0;   // (.. the most one rank puts on ONE link within one panel's exchange)   // bytes this rank sends to ONE peer per fit; device time of the owner-only work per fit; panels exchanged by row pieces
     std::vector<hipEvent_t> ev_own;                                  // (pairs of stamps around the owner-only work of this rank's panels)
   } dc;
-  int opt_dist_split = 0;                      // sharded fit, panel exchange by ROW PIECES: the owner factors only the panel's W x W top block and broadcasts it; every rank
+  int opt_dist_la2d = 1;                       // row-split exchange: the NEXT panel's first update divided by rows as well (see shard_factor): 0 = the next owner applies it alone
+  int opt_dist_split = -1;  /* -1 = by the number of ranks (on from four ranks) */                      // sharded fit, panel exchange by ROW PIECES: the owner factors only the panel's W x W top block and broadcasts it; every rank
                                                // solves 1/world of the rows below it (scattered to it) and an all-gather assembles the panel -- instead of one
                                                // rank solving all rows and broadcasting the panel.  Same arithmetic per row: bit-identical results.
   int opt_dist_seg = 2;                        // sharded fit: column blocks per streamed broadcast segment (>= panel width: the panel travels whole)
@@ -1196,7 +1198,7 @@ int trtri_levels(sigp_handle* h, hipStream_t st, const Real* Lm, long ldl, const
 // =====================================================================================================
 extern "C" {
 
-int sigp_version(void) { return 400; }   // 3.0: the sharded fit inside the library (sigp_dist_init / _fit), sigp_runtime_info, sigp_nlml_grad_batch
+int sigp_version(void) { return 500; }   // 4.0: sigp_transport grew scatter / allgather (3.x callers: sigp_dist_init_transport2 with their struct's size); 5.0: sigp_small_run_grad, sigp_small_set_dweights, sigp_dist_init_transport2
 
 // which HIP runtime serves this process (a process that also loads PyTorch-ROCm has two on disk; the first one mapped wins)
 int sigp_runtime_info(char* buf, int64_t len) {
@@ -1293,7 +1295,8 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "owner_only")) { h->opt_owner_only = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_timeout_ms")) { if (value < 0) return SIGP_BAD_ARG; h->opt_dist_timeout_ms = (long)value; return SIGP_OK; }
   if (!strcmp(name, "dist_stats")) { h->opt_dist_stats = value != 0; return SIGP_OK; }
-  if (!strcmp(name, "dist_panel_split")) { h->opt_dist_split = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "dist_panel_split")) { if (value < -1 || value > 1) return SIGP_BAD_ARG; h->opt_dist_split = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "dist_lookahead2d")) { h->opt_dist_la2d = value != 0; return SIGP_OK; }
   if (!strcmp(name, "dist_segment")) { if (value < 1 || value > 64) return SIGP_BAD_ARG; h->opt_dist_seg = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_ll")) { if (value < 0 || value > 64) return SIGP_BAD_ARG; h->opt_panel_ll = (int)value; return SIGP_OK; }
   if (!strcmp(name, "trsm128_threshold")) { if (value < 0) return SIGP_BAD_ARG; h->opt_trsm128 = (int)value; return SIGP_OK; }

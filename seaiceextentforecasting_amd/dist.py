@@ -238,7 +238,7 @@ class DistributedGPR:
         self._cb = (L.BCAST_FN(bcast), L.ALLREDUCE_FN(allreduce), L.SCATTER_FN(scatter), L.ALLGATHER_FN(allgather))
         self._tr = L.Transport(None, 0, self._cb[0], self._cb[1], self._cb[2], self._cb[3])
         gp = self.gp
-        gp._check(gp._lib.sigp_dist_init_transport(gp._h, self.world, self.rank, C.byref(self._tr)), "dist_init_transport")
+        gp._check(gp._lib.sigp_dist_init_transport2(gp._h, self.world, self.rank, C.byref(self._tr), C.sizeof(self._tr)), "dist_init_transport")
         self.transport = "host"
 
     def close(self):

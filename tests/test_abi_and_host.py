@@ -458,18 +458,22 @@ def test_plain_c_program_runs_the_hot_path_and_the_sharded_fit(tmp_path):
 
 
 def test_committed_pmc_summary_belongs_to_the_committed_kernel_code():
-    """bench.py quotes roofline.traffic from profiles/r04_pmc_syrk128.json only while the sha of the kernel sources recorded in it equals the
+    """bench.py quotes roofline.traffic from profiles/r05_pmc_syrk128.json only while the sha of the kernel sources recorded in it equals the
     tree's (a stale file is refused, and the line then carries traffic = null).  The file committed with the tree must be the tree's."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root)
     import bench
-    pm = json.load(open(os.path.join(root, "profiles", "r04_pmc_syrk128.json")))
+    pm = json.load(open(os.path.join(root, "profiles", "r05_pmc_syrk128.json")))
     assert pm["kernel_code_sha16"] == bench.kernel_code_sha16()
     assert pm["traffic_bytes_per_launch"] > 0 and 0.5 < pm["mfma_pipe_busy_fraction"] <= 1.0
-    for other in ("r04_pmc_kbuild.json", "r04_pmc_syrk128_f32.json"):        # the round's other PMC summaries exist and carry what DESIGN.md quotes from them
+    for other in ("r05_pmc_kbuild.json", "r05_pmc_syrk128_f32.json"):        # the round's other PMC summaries exist and carry what DESIGN.md quotes from them
         d = json.load(open(os.path.join(root, "profiles", other)))
         assert d.get("hbm_total_GBps", d.get("tflops_in_kernel", 0)) > 0, other
+    ch = json.load(open(os.path.join(root, "profiles", "r05_pmc_chain_kernels.json")))        # the panel stream's kernels (VERDICT r4 item 6), same passes, same code
+    assert ch["kernel_code_sha16"] == bench.kernel_code_sha16()
+    for k in ("diag_update_kernel<double", "panel_strip_kernel<double", "chain_link_kernel<double"):
+        assert ch["kernels"][k]["rocprofv3_stats_avg_ms"] > 0 and 0 <= ch["kernels"][k]["mfma_pipe_busy_fraction"] <= 1.0, k
 
 
 def test_bench_compact_line_fits_the_drivers_tail():

@@ -54,6 +54,8 @@ def test_transport_struct_matches_the_header():
 def test_sharded_fit_rejects_bad_arguments_without_a_gpu():
     from seaiceextentforecasting_amd import _lib as L
     lib = L.load()
+    assert lib.sigp_version() >= 500                                       # sigp_dist_init_transport2 (a caller's struct size travels with the struct)
+    assert lib.sigp_dist_init_transport2(None, 2, 0, None, 48) == L.BAD_ARG
     assert lib.sigp_dist_unique_id(None) == L.BAD_ARG
     assert lib.sigp_dist_init(None, 2, 0, None) == L.BAD_ARG
     assert lib.sigp_dist_init_transport(None, 2, 0, None) == L.BAD_ARG

@@ -34,11 +34,10 @@ for b in range(nb):
     print("  %5.1f ms  %s" % ((a - t0) / 1e6, "  ".join(row)))
 
 if cp_out:
-    dom = fit[fit['name'].str.startswith('syrk128_kernel<double, false')]
-    if len(dom) == 0:
-        dom = fit[fit['name'].str.startswith('syrk128_kernel<float, false')]
-    qd = dom['Queue_Id'].iloc[0]
+    # the update queue is the one the step's covariance build runs on (in-panel updates on the panel stream use the same tile kernel)
+    qd = fit[fit['name'].str.startswith(mark)]['Queue_Id'].iloc[0]
     upd = fit[fit['Queue_Id'] == qd].sort_values('Start_Timestamp')
+    dom = upd[upd['name'].str.startswith('syrk128_kernel<double, false') | upd['name'].str.startswith('syrk128_kernel<float, false')]
     oth = fit[fit['Queue_Id'] != qd]
     gaps = []          # (start, end, kind)
     first, last = dom['Start_Timestamp'].min(), dom['End_Timestamp'].max()
