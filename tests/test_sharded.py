@@ -112,7 +112,9 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
                 ref2 = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
                 assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la, rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]))
                 mu3, var3 = dg.predict(Xn[3:4])              # again (alpha~ and the inverses are kept), one point
-                assert np.array_equal(mu3, mu2[3:4]) and np.array_equal(var3, var2[3:4])
+                # (the mean is formed on every rank alike; the variance's partial sums go through the TRANSPORT's all-reduce, whose order of
+                #  summation over three or more ranks may depend on the message length -- gloo's does: one ulp of k*^T K~^-1 k* ~ 1, times sigma_f)
+                assert np.array_equal(mu3, mu2[3:4]) and np.allclose(var3, var2[3:4], rtol=0, atol=(0 if world < 3 else 1e-15 * dg.sigma_f_))
             dg.fit(X, 2.0 * y, ell, sn, Xs=Xs)               # handle / buffer reuse
             assert rel(dg.predict(Xs)[0], 2.0 * ref["fmean"]) <= 1e-8
             # a bad hyper-parameter (an optimiser proposing l <= 0 / sn~ < 0) is an argument error on every rank alike, raised before any
@@ -141,6 +143,13 @@ for kind, n, d, W in (("rbf", 2100, 8, 2), ("netdiffusion", 1300, 12, 1), ("mate
                 mu2, var2 = dg.predict(Xn)
                 ref2 = O.fit_predict(X, y, Xn, ell, sn, kind=kind, ref_idiom=False)
                 assert rel(mu2, ref2["fmean"]) <= 1e-8 and rel(var2, ref2["fvar"]) <= 1e-8, (kind, rank, la, "split", rel(mu2, ref2["fmean"]), rel(var2, ref2["fvar"]))
+            # ... and with the next panel's first update applied by its owner alone (dist_lookahead2d = 0; the default divides it by rows: hot rows
+            # + top-block update on the next owner, the rows below updated piece by piece where they are solved): a schedule, the same bits
+            dg.gp.set_option("dist_lookahead2d", 0)
+            dg.refit(ell, sn)
+            mu0, var0 = dg.predict(Xs)
+            assert np.array_equal(mu0, bits[0][0]) and np.array_equal(var0, bits[0][1]) and dg.nlml_ == bits[0][2], (kind, n, W, la, "first update by rows changed the bits")
+            dg.gp.set_option("dist_lookahead2d", 1)
     # the streamed broadcast: segments of 1 / 3 column blocks and whole panels -- the next owner then applies K = 128 / 384 / W 128
     # updates instead of K = 256 ones: same k order per tile, so the same bits
     for seg in (1, 3, 64):
@@ -223,7 +232,7 @@ def _torchrun(script, world, port, timeout):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [1, 2, 3])
+@pytest.mark.parametrize("world", [1, 2, 3, 4])
 def test_sharded_fit_inside_the_library(tmp_path, world):
     """sigp_dist_fit at test sizes, fp64 and fp32, world 1-3: == oracle on every rank, == the single-GPU engine, bit-identical
     with and without look-ahead, per-rank matrix bytes ~ 1/world, non-SPD exit on every rank, handle reuse."""
