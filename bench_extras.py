@@ -106,6 +106,7 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
         with DistributedGPR(kind, rank, world, dist, device=local, outer_blocks=outer, dtype=dtype, stats=True) as dg:
             times = []
             dg.fit(X, y, ell, sn, Xs=Xs)          # stages X, y, Xs on every rank, allocates, opens the ring
+            dg.gp.set_option("dist_panel_split", 0)    # the streamed whole-panel broadcast first (from four ranks on the row-split exchange is the default: it is timed below)
             for r_ in range(reps + 1):
                 torch.cuda.synchronize()
                 if dist is not None:
@@ -142,7 +143,7 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
             # (a collective that times out marks the handle dead) must not cost the record the numbers above
             splitt, st_split, split_nlml, split_err = [], dict(st), float("nan"), None
             try:
-                dg.gp.set_option("dist_panel_split", 1)
+                dg.gp.set_option("dist_panel_split", 1)          # (with the next panel's first update divided by rows: dist_lookahead2d, default)
                 dg.refit(ell, sn)
                 for r_ in range(reps):
                     torch.cuda.synchronize()
@@ -187,6 +188,21 @@ def sharded_record(rank, world, local, dist, backend, configs=("configs[3]", "co
                                     "rel_diff_nlml_vs_whole_panel_exchange": float(abs(split_nlml - res["nlml"]) / abs(res["nlml"])),
                                     "error": split_err,
                                     "note": "dist_panel_split = 1: top block broadcast (8 MB at W = 8), rows below scattered in `world` pieces, solved where they land, all-gathered in place"}}
+        # the model beside the measurement: with the row-split exchange and the next panel's first update divided by rows, what is
+        # left on the critical path of a panel is the owner's top-block chain + its hot rows (update, solve, one broadcast of W x W 128-blocks) + the next
+        # owner's top-block update; piece solves, all-gather and the rest of the update run beside the next chain.  Inputs: the owner-only device time
+        # per panel MEASURED in this run (max over ranks), 150 GB/s per xGMI link, the trailing-update rate of one GPU for the top-block update.
+        npan = max(1, -(-(n // 128) // outer))
+        esz = 8 if dtype == "f64" else 4
+        own_pp = float(vmax[7]) * world / npan                       # ms, row-split path (top chain + hot rows)
+        hot_bytes = (outer * 128) * (outer * 128) * esz
+        top_upd_ms = 1e3 * (outer * (outer + 1) / 2) * 2 * 128 * 128 * (outer * 128) / (60e12 if dtype == "f64" else 110e12)
+        e["critical_path_model"] = {"per_panel_ms": {"owner_top_chain_and_hot_rows_measured": own_pp, "hot_rows_broadcast_at_150GBps": 1e3 * hot_bytes / 150e9,
+                                                     "next_owners_top_block_update": top_upd_ms},
+                                    "panels": npan,
+                                    "ms_per_fit_if_everything_else_hides": npan * (own_pp + 1e3 * hot_bytes / 150e9 + top_upd_ms),
+                                    "note": "a MODEL: valid when piece solves + all-gather + the rest of the trailing update (1/world of it per rank) fit beside the next owner's chain; "
+                                            "measured ms_per_fit of this run is in row_split_exchange.ms_per_fit (ranks sharing one GPU over gloo measure correctness only)"}
         if "refinement_residual" in res:
             e["refinement_residual"] = res["refinement_residual"]
         if rank == 0:
