@@ -595,7 +595,7 @@ template <typename T>
 __global__ __launch_bounds__(DIAG_THREADS, 4) void diag_update_kernel(T* __restrict__ A, long lda, T* __restrict__ Linv, int* __restrict__ info,
                                                                    int pivot_base, int flags, long strideA, long strideL, int nb,
                                                                    GemmArgsT<T> g, int ntile, int wgs, const T* __restrict__ Balt, long sBalt,
-                                                                   T* __restrict__ copy_dst) {
+                                                                   T* __restrict__ copy_dst, int reps) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   if ((int)blockIdx.x < nb) {
     potrf_diag_body<T>(A + blockIdx.x * strideA, lda, Linv + blockIdx.x * strideL, info + blockIdx.x, pivot_base, flags, smem_raw);
@@ -614,18 +614,31 @@ __global__ __launch_bounds__(DIAG_THREADS, 4) void diag_update_kernel(T* __restr
     }
     return;
   }
+  // A riding workgroup takes `reps` consecutive tile pairs (option ride_reps; 1 by default).  Beside the trailing update of a lockstep batch a
+  // workgroup of this kernel gets onto a CU only when one of its two resident update workgroups retires (their 8 waves hold all of the CU's
+  // vector registers): the 6 720 two-tile workgroups of a 160-member launch are admitted at ~1.5 per microsecond -- 4.4 ms per launch for
+  // 0.5 ms of MFMA work.  Longer runs per admitted workgroup make the launch 3-4 x shorter -- and the update launches beside it as much
+  // longer: the batch is bound by the sum of its MFMA work (docs/EXPERIMENTS.md), so the default stays 1.  Same tiles, same arithmetic.
   const int bz = u / wgs, w = u - bz * wgs;
   const int e = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
-  int t = 2 * w + e;
-  const bool own = t < ntile;
-  if (!own) t = ntile - 1;          // odd tile count: the last workgroup's second engine shadows the first (no store)
-  int bi = 0, bj = 0;
-  gemm_tile_coords(g, t, bi, bj);
-  GemmArgsT<T> gl = g;
-  if (Balt != nullptr && bj < 2) {  // block column c+1: its rows of column c are still in the link's scratch block
-    gl.B = Balt; gl.ldb = DB; gl.sB = sBalt;
+#pragma unroll 1
+  for (int rep = 0; rep < reps; ++rep) {
+    const int t0 = 2 * (w * reps + rep);
+    if (t0 >= ntile) break;           // (uniform)
+    if (rep) __syncthreads();         // every wave is done with the engines' LDS images of the last pair
+    int t = t0 + e;
+    const bool own = t < ntile;
+    if (!own) t = ntile - 1;          // odd tile count: the last pair's second engine shadows the first (no store)
+    int bi = 0, bj = 0;
+    gemm_tile_coords(g, t, bi, bj);
+    GemmArgsT<T> gl = g;
+    if (Balt != nullptr && bj < 2) {  // block column c+1: its rows of column c are still in the link's scratch block
+      gl.B = Balt; gl.ldb = DB; gl.sB = sBalt;
+    }
+    int tl = (int)threadIdx.x & 255;
+    asm volatile("" : "+v"(tl));      // (the tile body's per-lane offsets are recomputed per pair: hoisted out of this loop they cost the kernel 20 spilled registers)
+    gemm_tile_body<T, 64, 64, 2, 2, GEMM_SUB, false, 2>(gl, bi, bj, (long)bz, tl, smem_raw + e * gemm_lds_bytes<T, 64, 64, false>(), own);
   }
-  gemm_tile_body<T, 64, 64, 2, 2, GEMM_SUB, false, 2>(gl, bi, bj, (long)bz, (int)threadIdx.x & 255, smem_raw + e * gemm_lds_bytes<T, 64, 64, false>(), own);
 }
 
 }  // namespace sigp

@@ -189,6 +189,7 @@ struct sigp_handle {
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
   int ncu = 256;              // compute units of the device
+  int opt_ride_reps = 0;      // tile pairs per riding workgroup of diag_update_kernel: 0 = one (default), n = fixed, -1 = by the launch (about four riders per CU): measured neutral, see docs/EXPERIMENTS.md
   int opt_kbuild_mfma = 2;   // covariance build: squared distances in GEMM form on the matrix pipe (kbuild_mfma_kernel): 2 = from 16 features on (below, the 2 d
                              // VALU instructions per element are not what the build waits for: same time either way), 1 = always, 0 = never (VALU)
   int opt_diag_prio = 1;     // diagonal-block kernel raises its wave priority (s_setprio 3)
@@ -617,11 +618,15 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
     ProfScope ps(h, sp, SIGP_KC_DIAG, nb * 2.0 * NB * NB * NB / 3 + uflops, nb * 3.0 * NB * NB * 8 + nb * (double)ntile * 2.0 * 64 * 64 * sizeof(Real));
     Real* Ac = Mm + (long)c * NB * ld + (long)c * NB;
     if (ntile > 0 || linked) {
-      const int wgs = (ntile + 1) / 2;
+      // tile pairs per riding workgroup: in lockstep batches so many that about four riders per CU are left (see diag_update_kernel)
+      const int pairs = (ntile + 1) / 2;
+      const long want = h->opt_ride_reps > 0 ? h->opt_ride_reps : (h->opt_ride_reps < 0 ? ((long)nb * pairs + 4L * h->ncu - 1) / (4L * h->ncu) : 1);
+      const int reps = (int)std::max<long>(1, std::min<long>(want, 32));
+      const int wgs = (pairs + reps - 1) / reps;
       GemmArgsT<Real> g0{};
       hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(nb + nb * wgs + (linked ? nb : 0)), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info,
                          c * NB, flags, matStride, dinvStride, nb, gu ? *gu : g0, ntile, wgs, linked ? (const Real*)lk : (const Real*)nullptr, (long)NB * NB,
-                         linked ? Ac - NB : (Real*)nullptr);
+                         linked ? Ac - NB : (Real*)nullptr, reps);
     } else {
       hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB, flags, matStride,
                          dinvStride);
@@ -756,9 +761,12 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
       static AttrOnce du_attr;
       constexpr int du_lds = std::max(diag_lds, 2 * gemm_lds_bytes<Real, 64, 64, false>());   // (fp32: the two update engines need more than the block)
       HIPCHK(h, du_attr.set(h->device, (const void*)diag_update_kernel<Real>, du_lds));
-      const int wgs = (ntile + 1) / 2;
+      const int pairs = (ntile + 1) / 2;
+      const long want = h->opt_ride_reps > 0 ? h->opt_ride_reps : (h->opt_ride_reps < 0 ? ((long)nb * pairs + 4L * h->ncu - 1) / (4L * h->ncu) : 1);
+      const int reps = (int)std::max<long>(1, std::min<long>(want, 32));
+      const int wgs = (pairs + reps - 1) / reps;
       hipLaunchKernelGGL(diag_update_kernel<Real>, dim3(nb + nb * wgs), dim3(DIAG_THREADS), du_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info,
-                         c * NB, flags, matStride, dinvStride, nb, *gu, ntile, wgs, (const Real*)nullptr, 0L, (Real*)nullptr);
+                         c * NB, flags, matStride, dinvStride, nb, *gu, ntile, wgs, (const Real*)nullptr, 0L, (Real*)nullptr, reps);
     } else {
       hipLaunchKernelGGL(potrf_diag_kernel<Real>, dim3(nb), dim3(DIAG_THREADS), diag_lds, sp, Ac, ld, dinvp + (long)c * NB * NB, s.info, c * NB,
                          flags, matStride, dinvStride);
@@ -1282,6 +1290,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   if (!strcmp(name, "refine_tol_e")) { if (value < 0 || value > 16) return SIGP_BAD_ARG; h->opt_refine_tol_e = (int)value; return SIGP_OK; }
   if (!strcmp(name, "refine_iters")) { if (value < 0 || value > 20) return SIGP_BAD_ARG; h->opt_refine_iters = (int)value; return SIGP_OK; }
   if (!strcmp(name, "panel_mode")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_panel_mode = (int)value; return SIGP_OK; }
+  if (!strcmp(name, "ride_reps")) { if (value < -1 || value > 64) return SIGP_BAD_ARG; h->opt_ride_reps = (int)value; return SIGP_OK; }
   if (!strcmp(name, "kbuild_mfma")) { if (value < 0 || value > 2) return SIGP_BAD_ARG; h->opt_kbuild_mfma = (int)value; return SIGP_OK; }
   if (!strcmp(name, "diag_prio")) { h->opt_diag_prio = value != 0; return SIGP_OK; }
   if (!strcmp(name, "update_dbg")) { h->opt_update_dbg = (int)value; return SIGP_OK; }
