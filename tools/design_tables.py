@@ -1,8 +1,8 @@
 """Regenerate the measured tables of DESIGN.md (between the GENERATED markers) from profiles/<round>_*: every figure names the file it comes from.
-    python tools/design_tables.py [r04]        (rewrites DESIGN.md in place; prints the tables)"""
+    python tools/design_tables.py [r05]        (rewrites DESIGN.md in place; prints the tables)"""
 import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = lambda name: os.path.join(ROOT, "profiles", "%s_%s" % (R, name))
 v = json.load(open(P("bench_line_verbose.json")))
 pm = json.load(open(P("pmc_syrk128.json")))
@@ -90,7 +90,36 @@ A("| MLII (nlML + exact gradient) | single fit: %.2f ms at n = 4096, %.2f ms at 
 rk = oc.get("reference_kernel_grid", {})
 A("| reference kernel at reference size: 3 regions x 40 years x 20 x 20 grid = %d fits, one launch | %.2f ms per call (%.1f M fits/s incl. copies) vs %.1f k fits/s for the oracle's loop on the host | |"
   % (rk.get("fits", 0), rk.get("ms_per_launch", 0), rk.get("fits_per_s", 0) / 1e6, rk.get("cpu_oracle_loop", {}).get("fits_per_s", 0) / 1e3))
+rm = oc.get("reference_kernel_mlii", {})
+if rm and "evaluations_per_s" in rm:
+    op = rm.get("optimise_120_region_years", {})
+    A("| the reference's MLII closure for its own kernel, batched: %d evaluations (value + reference \"gradient\" + exact gradient), one launch | %.2f ms per call (**%.1f M evaluations/s**); the optimiser of `:259-262` for 120 (region, year) data sets in lockstep: %d launches, %.0f ms, %d converged | |"
+      % (rm.get("evaluations", 0), rm.get("ms_per_launch", 0), rm.get("evaluations_per_s", 0) / 1e6, op.get("launches", 0), 1e3 * op.get("seconds", 0), op.get("converged", 0)))
 A("")
+try:
+    ch = json.load(open(P("pmc_chain_kernels.json")))
+    A("**The panel stream's kernels** in the same bench command (`profiles/%s_pmc_chain_kernels.json`: PMC passes serialise kernels, so the counters are each kernel ALONE on the chip; the durations are from `--kernel-trace --stats` of the normal run, beside the trailing update):" % R)
+    A("")
+    A("| kernel | launches per command | avg ms (beside the update) | total ms | MFMA pipe busy | CU busy | LDS bank conflicts / LDS-active cycles | HBM bytes per launch (fetch x 2 + write) |")
+    A("|---|---|---|---|---|---|---|---|")
+    names = {"diag_update_kernel<double": "`diag_update_kernel` (diagonal blocks + riding in-panel updates)", "panel_strip_kernel<double": "`panel_strip_kernel` (rows below a panel's top block)",
+             "chain_link_kernel<double": "`chain_link_kernel`", "potrf_diag_kernel<double": "`potrf_diag_kernel` (first block of a panel)", "syrk128_kernel<double, true": "`syrk128_kernel<double, SET>` (column solves)"}
+    for k, e in ch["kernels"].items():
+        A("| %s | %d | %.3f | %.1f | %s | %s | %s | %.2f GB |" % (names.get(k, k), e["rocprofv3_stats_calls"], e["rocprofv3_stats_avg_ms"], e["rocprofv3_stats_total_ms"],
+          ("%.2f" % e["mfma_pipe_busy_fraction"]) if e.get("mfma_pipe_busy_fraction") is not None else "n/a", ("%.2f" % e["cu_busy_fraction"]) if "cu_busy_fraction" in e else "n/a",
+          ("%.2f" % e["lds_bank_conflict_fraction"]) if "lds_bank_conflict_fraction" in e else "n/a", (e["fetch_bytes_per_launch_corrected"] + e["write_bytes_per_launch"]) / 1e9))
+    A("")
+except OSError:
+    pass
+try:
+    cp = json.load(open(P("critical_path.json")))
+    ui = cp["update_queue_idle_ms"]
+    A("**Where the update queue idles inside one step** (`profiles/%s_critical_path.json`, from the kernel trace of `profiles/%s_trace_batch_group.txt`): step %.1f ms, update queue busy %.1f ms, idle %.1f ms = head %.1f (covariance build on the same queue excluded; first panel: %s) + between trailing updates %.1f (late panels: %s) + tail %.1f."
+      % (R, R, cp["step_ms"], cp["update_queue_busy_ms"], ui["total"], ui["head"], ", ".join("%s %.1f" % kv for kv in list(cp["other_queue_during_idle_ms"]["head"].items())[:3]), ui["between"],
+         ", ".join("%s %.1f" % kv for kv in list(cp["other_queue_during_idle_ms"]["between"].items())[:3]), ui["tail"]))
+    A("")
+except OSError:
+    pass
 A("<!-- END GENERATED -->")
 txt = "\n".join(out)
 print(txt)
