@@ -292,13 +292,19 @@ int sigp_synchronize(sigp_handle* h);
  *   refine_sym [1]        ... reading the stored lower triangle ONCE per residual (4 n^2 bytes; row and column sums of every tile from LDS), 0 = in two passes
  *   owner_only [0]        sigp_set_train does not allocate the n x n single-GPU matrix (sigp_dist_fit); dist_stats [0] see sigp_dist_fit;
  *   dist_segment [2]      column blocks per streamed broadcast segment of the sharded fit (>= the panel width: panels travel whole)
- *   dist_panel_split [0]  sharded fit, panel exchange by ROW PIECES ("all-gather of block-row pieces"): the owner factors only the panel's W x W top
+ *   dist_panel_split [-1] (-1 = by the number of ranks: on from four; 0 / 1)  sharded fit, panel exchange by ROW PIECES ("all-gather of block-row pieces"): the owner factors only the panel's W x W top
  *                         block and broadcasts it (8 MB at W = 8); the rows below it are scattered in `world` pieces, every rank solves its piece, and
  *                         an in-place all-gather assembles the panel on every rank -- the owner's throughput work leaves the chain and each link carries
  *                         1/world of the panel instead of all of it.  Rows are independent: bit-identical to dist_panel_split = 0 wherever both run the same
  *                         tile kernels (every order up to ~ 10 000 at W = 8); beyond, a whole panel's in-panel updates go to the 128-tile kernel and a
  *                         row piece's do not (another k order inside a 16-slice): last-bit differences.
- *   dist_timeout_ms [120000] deadline of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
+ *   dist_lookahead2d [1]  with the row-split exchange: the NEXT panel's first update is divided by rows as well -- every rank applies it to its own piece
+ *                         before solving it; the next owner keeps the update of its top block (from the rows right below the panel's top block, which the
+ *                         owner solves itself behind its chain and broadcasts ahead of the pieces) and starts its chain beside the piece solves and the
+ *                         all-gather.  A schedule: bit-identical to 0 at every tested shape.
+ *   ride_reps [0]         tile pairs per riding workgroup of the diagonal-block launch (0 = one; -1 = by the launch, about four riders per CU; n = fixed):
+ *                         shortens that launch in lockstep batches and lengthens the trailing update beside it by as much (docs/EXPERIMENTS.md)
+ *   dist_timeout_ms [120000] deadline (time WITHOUT progress of the update stream's panel counter) of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
  *                         error / when it passes: ncclCommAbort, SIGP_HIP_ERROR (the panel reached is in sigp_last_error), the handle's sharded
  *                         state is dead until sigp_dist_shutdown + a fresh sigp_dist_init* -- a dead peer is an error, not a hang; 0 = wait for ever
  *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:
