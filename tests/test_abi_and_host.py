@@ -534,3 +534,35 @@ def test_lockstep_optimiser_drivers_on_the_oracle():
         sc = minimize(lambda t: O.mlii(t, X, y, M=M, grad="exact"), x0[i], jac=True, method="L-BFGS-B")
         for r in (rn, rb):
             assert r["fun"][i] <= sc.fun + 1e-6 * max(1.0, abs(sc.fun)) and np.max(np.abs(r["jac"][i])) <= 1e-4
+
+
+def test_diagonal_block_role_map_is_a_permutation_for_every_simd_placement(tmp_path):
+    """potrf_diag.hpp deals the eight waves' roles by the SIMD each wave sits on (read from HW_ID at run time).  Whatever the placement --
+    all 4^8 tables -- the map must be a permutation of the roles: compiled for the host from the header's own text and brute-forced."""
+    import re
+    hdr = open(os.path.join(ROOT, "seaiceextentforecasting_amd", "csrc", "potrf_diag.hpp")).read()
+    m = re.search(r"__device__ inline int diag_logical_wave\(.*?\n}\n", hdr, flags=re.S)
+    assert m, "diag_logical_wave not found"
+    body = m.group(0).replace("const volatile int* tab", "const int* tab")
+    src = tmp_path / "roles.cpp"
+    src.write_text('#include <cstdio>\n#define __device__\nstatic inline int __builtin_amdgcn_readfirstlane(int x) { return x; }\n' + body + r'''
+int main() {
+  long bad = 0;
+  for (int code = 0; code < 65536; ++code) {
+    int tab[8];
+    for (int w = 0; w < 8; ++w) tab[w] = (code >> (2 * w)) & 3;
+    unsigned seen = 0;
+    for (int pw = 0; pw < 8; ++pw) { const int r = diag_logical_wave(tab, pw); if (r >= 0 && r < 8) seen |= 1u << r; }
+    bad += seen != 0xffu;
+  }
+  int usual[8] = {0, 2, 1, 3, 0, 2, 1, 3};       // observed placement: the pivot wave's SIMD mate is the store wave, (1, 6), (2, 3), (4, 5) are SIMD pairs
+  const bool ok = diag_logical_wave(usual, 0) == 0 && diag_logical_wave(usual, 4) == 7 && diag_logical_wave(usual, 1) == 1 && diag_logical_wave(usual, 5) == 6
+                  && diag_logical_wave(usual, 2) == 2 && diag_logical_wave(usual, 6) == 3;
+  std::printf("%ld %d\n", bad, (int)ok);
+  return 0;
+}
+''')
+    exe = tmp_path / "roles"
+    subprocess.check_call(["g++", "-O1", "-o", str(exe), str(src)])
+    out = subprocess.check_output([str(exe)], text=True).split()
+    assert out == ["0", "1"], out
