@@ -124,14 +124,6 @@ class SmallBatch:
         self._fits = []
         self._packed = None
 
-    def evaluate(self, ds, ell, sn_tilde, expm="eigh", grad=True):
-        """Replace the queue by fit i = data set ds[i] at (ell[i], sn_tilde[i]) and run it: what one round of a lockstep optimiser
-        over all (region, year) data sets asks for.  With expm="eigh" nothing but the 24 bytes per fit crosses the bus."""
-        self.clear_fits()
-        for d, e, s_ in zip(ds, ell, sn_tilde):
-            self.add_fit(int(d), e, s_, expm=expm)
-        return self.run(grad=grad)
-
     def run(self, grad=False):
         """All queued fits in one launch -> dict(sigma_f, nlml, info, sigma_n, mean [F, mmax], var [F, mmax]); with ``grad=True``
         also grad_ref [F, 2] (the reference's MLII formulae, north/June1st.py:248-252) and grad_exact [F, 2] (the derivative of the
