@@ -159,6 +159,8 @@ def main():
     # imported before the library there, see _lib.load).
     torch = dist = None
     backend = os.environ.get("SIGP_BENCH_BACKEND", "nccl")      # "gloo" lets two ranks rehearse on one GPU
+    if world > 1 and rank == 0 and not args.no_sharded:
+        start_line_guardian()
     if world > 1:
         import torch
         import torch.distributed as dist
@@ -313,6 +315,8 @@ def main():
         if out.get("cpu_baseline", {}).get("value"):
             out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]     # (vs_baseline stays null: the reference publishes no number for this metric)
     if world > 1 and not args.no_sharded:
+        if rank == 0:
+            emit_provisional(out)
         X_.sharded_with_watchdog(out, args, rank, world, local, dist, backend, emit)
     if rank == 0:
         emit(out)
@@ -403,6 +407,57 @@ def compact_line(out):
     return c
 
 
+_guard_fd = None      # rank 0, N > 1: write end of the pipe to the child that owns stdout's one line
+_guard_pid = None
+
+
+def start_line_guardian():
+    """N > 1, rank 0, BEFORE anything touches the GPU (a plain fork, no exec): a child that owns the metric line.  Rank 0 hands it
+    the line measured so far before it enters the untimed sharded fits (never yet run on more than one real GPU) and the final line
+    after them; the child prints the LAST line it was given when the pipe closes -- so stdout carries exactly one line whether rank 0
+    finishes, is cut off by the watchdog, or dies inside a collective."""
+    global _guard_fd, _guard_pid
+    r, w = os.pipe()
+    sys.stdout.flush(); sys.stderr.flush()
+    pid = os.fork()
+    if pid == 0:
+        os.close(w)
+        last = b""
+        with os.fdopen(r, "rb") as f:
+            for ln in f:
+                if ln.strip():
+                    last = ln
+        if last:
+            os.write(1, last if last.endswith(b"\n") else last + b"\n")
+        os._exit(0)
+    os.close(r)
+    _guard_fd, _guard_pid = w, pid
+
+
+def guardian_hand_over(line, final):
+    """The metric line goes to the guardian (or straight to stdout when there is none); `final` closes the pipe and waits for the child's print."""
+    global _guard_fd
+    if _guard_fd is None:
+        if final:
+            print(line, flush=True)
+        return
+    os.write(_guard_fd, line.encode() + b"\n")
+    if final:
+        os.close(_guard_fd)
+        _guard_fd = None
+        try:
+            os.waitpid(_guard_pid, 0)
+        except OSError:
+            pass
+
+
+def emit_provisional(out):
+    """Before the sharded record: the line as it stands, for the guardian to print should this process not come back."""
+    tmp = dict(out)
+    tmp["sharded"] = {"error": "rank 0 did not return from the sharded record (line handed over before it)"}
+    guardian_hand_over(json.dumps(compact_line(tmp)), final=False)
+
+
 def emit(out):
     """Rank 0: the full record to stderr and gpurun_out/bench_verbose.json, then -- LAST, and the only line on stdout -- the compact metric line."""
     txt = json.dumps(out)
@@ -413,8 +468,7 @@ def emit(out):
             f.write(txt + "\n")
     except OSError:
         pass
-    line = json.dumps(compact_line(out))
-    print(line, flush=True)
+    guardian_hand_over(json.dumps(compact_line(out)), final=True)
 
 
 def kernel_code_sha16():

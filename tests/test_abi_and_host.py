@@ -566,3 +566,24 @@ int main() {
     subprocess.check_call(["g++", "-O1", "-o", str(exe), str(src)])
     out = subprocess.check_output([str(exe)], text=True).split()
     assert out == ["0", "1"], out
+
+
+def test_bench_line_guardian_prints_exactly_one_line_whatever_happens_to_rank0():
+    """N > 1: rank 0 hands the metric line to a forked child before it enters the (never multi-GPU-run) sharded fits.  The child prints
+    the LAST line it was given: the final one on a normal end, the provisional one when rank 0 is killed in between, nothing when
+    there was none."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    head = "import os, sys, signal; sys.path.insert(0, %r); import bench; bench.start_line_guardian(); " % root
+    cases = {
+        "bench.guardian_hand_over('PROVISIONAL', final=False); bench.guardian_hand_over('FINAL', final=True)": "FINAL\n",
+        "bench.guardian_hand_over('PROVISIONAL', final=False); os.kill(os.getpid(), signal.SIGKILL)": "PROVISIONAL\n",
+        "bench.guardian_hand_over('PROVISIONAL', final=False); os._exit(3)": "PROVISIONAL\n",
+        "os._exit(0)": "",
+    }
+    for body, want in cases.items():
+        p = subprocess.run([sys.executable, "-c", head + body], capture_output=True, text=True, timeout=120)
+        assert p.stdout == want, (body, p.stdout, p.stderr[-300:])
+    # without a guardian (N = 1) the final line goes straight to stdout and a provisional one nowhere
+    p = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; bench.guardian_hand_over('P', final=False); "
+                        "bench.guardian_hand_over('F', final=True)" % root], capture_output=True, text=True, timeout=120)
+    assert p.stdout == "F\n"
