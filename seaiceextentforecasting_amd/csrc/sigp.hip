@@ -186,6 +186,7 @@ struct sigp_handle {
   int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
                              // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
   int opt_strip_min = 512;
+  int opt_strip_tri = 1;     // strip solves skip the zero tile-slices of the inverse diagonal blocks (0 = multiply the whole 128 x 128 block: same bits, 9 % more MFMAs)
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
   int ncu = 256;              // compute units of the device
@@ -866,10 +867,15 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     }
     {
       ProfScope ps(h, sp, SIGP_KC_TRSM, nb * (double)below * 2.0 * NB * NB * NB * (Wp * (Wp + 1) / 2), nb * (double)below * 2.0 * Wp * NB * NB * 8);
-      static AttrOnce strip_attr;
-      HIPCHK(h, strip_attr.set(h->device, (const void*)panel_strip_kernel<Real>, SY_LDS_BYTES));
+      static AttrOnce strip_attr, strip_attr_full;
       StripArgsT<Real> a{M, ld, matStride, mt, MT_LD, mtStride, J0 + Wp, J0, Wp};
-      hipLaunchKernelGGL(panel_strip_kernel<Real>, dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
+      if (h->opt_strip_tri) {
+        HIPCHK(h, strip_attr.set(h->device, (const void*)panel_strip_kernel<Real>, SY_LDS_BYTES));
+        hipLaunchKernelGGL(panel_strip_kernel<Real>, dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
+      } else {
+        HIPCHK(h, strip_attr_full.set(h->device, (const void*)panel_strip_kernel<Real, false>, SY_LDS_BYTES));
+        hipLaunchKernelGGL((panel_strip_kernel<Real, false>), dim3(below, nb), dim3(256), SY_LDS_BYTES, sp, a);
+      }
       HIPCHK(h, hipGetLastError());
     }
     return SIGP_OK;
@@ -1298,6 +1304,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     if (!DBG_MASK) return fail(h, SIGP_BAD_ARG, "c_dma is a measurement switch of libsigp_debug.so");
     h->opt_c_dma = value != 0; return SIGP_OK;
   }
+  if (!strcmp(name, "strip_tri")) { h->opt_strip_tri = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
   if (!strcmp(name, "small_nt64")) { h->opt_small_nt64 = value != 0; return SIGP_OK; }

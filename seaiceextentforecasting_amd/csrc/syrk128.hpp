@@ -31,10 +31,16 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // One 128x128 tile:  C (-)= A[128 x K] B[128 x K]^T.  Ag / Bg point at the tile's first A / B row, Cw at THIS WAVE's
 // 64x64 quadrant of the C tile.  All 256 threads of the workgroup call it together (it contains barriers); As / Bs are
 // the workgroup's LDS staging buffers.  On return every wave has issued its C stores (not yet waited for).
-template <typename T, bool SET, int ABL = 0>
+// TRI (panel_strip_kernel only): the LAST 128 columns of B are a lower-triangular block (B[c][k] = 0 for k > c: an inverse diagonal
+// block), so a 16-column tile of C needs only the k-groups up to its last column.  The wave's four 16-column tiles are then INTERLEAVED
+// (wave wn owns tiles wn, wn + 2, wn + 4, wn + 6 of the 128 columns instead of four consecutive ones: Cw points at column 16 wn) so that
+// both column waves of a row pair skip about the same share, and slice s' = 0 .. 7 of that K block issues the MFMAs of its tiles
+// jj >= ceil((s' - wn) / 2) only: 16 / 20 of 32 tile-slices for wn = 0 / 1.  The skipped products are exact zeros: same bits.
+template <typename T, bool SET, int ABL = 0, bool TRI = false, int WNC = 0>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
                                              long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1,
                                              int tid_in = -1) {
+  static_assert(!TRI || (SET && sizeof(T) == 8), "TRI: fp64 strip solves only (C is not read)");
   const int dbg = dbg_in & DBG_MASK;            // ablation bits: debug library only
   const bool stamp = stamp_in && DBG_MASK != 0;
   typedef Num<T> N_;
@@ -42,7 +48,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   typedef typename N_::v16_t v16_t;
   constexpr int KTe = N_::KT, NE = N_::NE;
   const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave index: scalar
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = TRI ? WNC : (wave & 1);      // TRI: the caller instantiates the tile once per column wave (WNC)
   const int lr = lane & 15, lq = lane >> 4;
   // fp32: the MFMA is issued with its operands swapped, D' = B_j A_i^T = (A_i B_j^T)^T, so that a lane's four accumulator registers are
   // four CONSECUTIVE COLUMNS of one row of C (row lr, columns 4 lq .. 4 lq + 3: v_mfma_f32_16x16x4_f32 puts row 4 lq + r, column lr of
@@ -128,7 +134,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   // fragment read offsets (elements) inside a row for k-group h = 0 / 1
   const int x = (lr >> 1) & 7;
   const int fo0 = ((lq ^ x) & 7) * NE, fo1 = (((4 + lq) ^ x) & 7) * NE;
-  const int arow0 = (wm * 64 + lr) * KTe, brow0 = (wn * 64 + lr) * KTe;
+  constexpr int JS = TRI ? 32 : 16;                 // columns between a wave's consecutive 16-column tiles
+  const int arow0 = (wm * 64 + lr) * KTe, brow0 = ((TRI ? wn * 16 : wn * 64) + lr) * KTe;
 
   // Software pipeline (2 LDS buffers, one barrier per K-slice, placed MID-slice):
   //   MFMA group 0 with the 8 group-1 fragment reads of slice s spread through it | barrier (slice s+1 landed, slice s fully read)
@@ -145,32 +152,36 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
   for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bs + brow0 + j * 16 * KTe + fo0);
+  for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bs + brow0 + j * JS * KTe + fo0);
   // The loads sit INSIDE the MFMA groups (sched_group_barrier recipes: one load, G/8 MFMAs, ...).  The DMA is unconditional inside the
   // steady-state loop (a branch would cut the scheduling region); the last two slices run without it.  ABL (debug library only):
   // bit 0 no in-loop DMA, bit 1 no in-loop fragment reads, bit 2 no MFMA -- timing ablations as template arguments, so that the product kernel
   // and the debug library's ABL = 0 kernel are the same code.
-  auto slice = [&](int s, auto with_dma) __attribute__((always_inline)) {
+  auto slice = [&](int s, auto with_dma, auto jmin_c) __attribute__((always_inline)) {
+    constexpr int JMIN = decltype(jmin_c)::value;       // first 16-column tile of the wave this slice multiplies (0 unless TRI)
+    constexpr int NM = NE * 4 * (4 - JMIN);             // MFMAs per group
+    constexpr int NP = NM < 8 ? NM : 8;                 // ... of which this many lead one load each
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
     const T* Bb = Bs + buf * SY_T * KTe + brow0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * 16 * KTe + fo1);
+    for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * JS * KTe + fo1);
     if (!(ABL & 4))
 #pragma unroll
     for (int e = 0; e < NE; ++e)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
+        for (int j = JMIN; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                       // reads early, one per MFMA (the first MFMA leads: its operands' wait -- lgkmcnt(0) --
+    for (int q = 0; q < NP; ++q) {                      // reads early, one per MFMA (the first MFMA leads: its operands' wait -- lgkmcnt(0) --
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // would otherwise wait for the first of these reads as well), then the rest of the group
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NE * 16 - 8, 0);
+    if (NP < 8) __builtin_amdgcn_sched_group_barrier(0x100, 8 - NP, 0);
+    if (NM > NP) __builtin_amdgcn_sched_group_barrier(0x008, NM - NP, 0);
     __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
     __builtin_amdgcn_sched_barrier(0);
@@ -181,7 +192,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(An + i * 16 * KTe + fo0);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bn + j * 16 * KTe + fo0);
+      for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bn + j * JS * KTe + fo0);
     }
     if (!(ABL & 4))
 #pragma unroll
@@ -189,8 +200,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
-    if (decltype(with_dma)::value) {
+        for (int j = JMIN; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
+    if (decltype(with_dma)::value && NM >= 16) {
       // the DMA first (it is waited for one group + one barrier later: every MFMA it is issued behind comes off its lead), then the reads
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
@@ -202,14 +213,26 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       }
-      __builtin_amdgcn_sched_group_barrier(0x008, NE * 16 - 16, 1);
+      if (NM > 16) __builtin_amdgcn_sched_group_barrier(0x008, NM - 16, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
   {
+    typedef std::integral_constant<int, 0> J0_;
     int s = 0;
-    for (; s + 2 < nst; ++s) slice(s, std::true_type{});
-    for (; s < nst; ++s) slice(s, std::false_type{});
+    if constexpr (TRI) {
+      const int s_tri = nst - SY_T / KTe;             // first slice of the triangular K block (K is a multiple of 128 here)
+      for (; s < s_tri; ++s) slice(s, std::true_type{}, J0_{});
+      // the eight slices of the triangular block, straight-line, with the first tile of each a compile-time constant: ceil((s' - wn) / 2).
+      // (A run-time switch inside a loop, or both column waves' sequences behind one branch, cost the register allocator ~1 KB of scratch.)
+#define SY_TRI_STEP(SP) \
+  slice(s_tri + SP, std::integral_constant<bool, (SP + 2 < 8)>{}, std::integral_constant<int, ((SP - WNC + 1) >> 1)>{});
+      SY_TRI_STEP(0) SY_TRI_STEP(1) SY_TRI_STEP(2) SY_TRI_STEP(3) SY_TRI_STEP(4) SY_TRI_STEP(5) SY_TRI_STEP(6) SY_TRI_STEP(7)
+#undef SY_TRI_STEP
+    } else {
+      for (; s + 2 < nst; ++s) slice(s, std::true_type{}, J0_{});
+      for (; s < nst; ++s) slice(s, std::false_type{}, J0_{});
+    }
   }
 #undef SY_ISSUE
   if (stamp) ph1 = __builtin_amdgcn_s_memtime();   // K loop issued
@@ -223,10 +246,10 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
           acc_t c;
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[r] = SET ? acc[i][j][r] : -acc[i][j][r];
-          *(acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * 16 + 4 * lq) = c;
+          *(acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * JS + 4 * lq) = c;
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+          for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * JS + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
         }
       }
   }
@@ -311,7 +334,8 @@ struct StripArgsT {
   int Wp;                          // panel width in column blocks
 };
 
-template <typename T>
+// TRI_ (default for fp64): the triangular last K block of every column product skips its zero tile-slices (syrk128_tile's TRI form).
+template <typename T, bool TRI_ = (sizeof(T) == 8)>
 __global__ __launch_bounds__(256, 2) void panel_strip_kernel(StripArgsT<T> g) {
   constexpr int KTe = Num<T>::KT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -324,12 +348,22 @@ __global__ __launch_bounds__(256, 2) void panel_strip_kernel(StripArgsT<T> g) {
   T* strip = g.M + bz * g.sM + (long)(g.rb0 + blockIdx.x) * SY_T * g.ld + (long)g.J * SY_T;
   const T* Mt = g.Mt + bz * g.sMt;
   for (int j = 0; j < g.Wp; ++j) {
-    syrk128_tile<T, true>(strip, g.ld, Mt + (long)j * SY_T * g.ldm, g.ldm, strip + (long)(wm * 64) * g.ld + (long)j * SY_T + wn * 64, g.ld,
-                          SY_T * (j + 1), 0, As, Bs, false, ph0, ph1);
+    constexpr bool TRI = TRI_ && sizeof(T) == 8;   // (the engine strip-solves fp64 panels only; the fp32 instantiation keeps the plain tile)
+    T* Cq = strip + (long)(wm * 64) * g.ld + (long)j * SY_T + wn * (TRI ? 16 : 64);
+    const T* Mj = Mt + (long)j * SY_T * g.ldm;
+    int tid_t = threadIdx.x;
+    asm volatile("" : "+v"(tid_t));             // opaque per column: the tile's lane-dependent addresses are formed inside the loop (hoisted, they spill)
+    if (!TRI || wn == 0) syrk128_tile<T, true, 0, TRI, 0>(strip, g.ld, Mj, g.ldm, Cq, g.ld, SY_T * (j + 1), 0, As, Bs, false, ph0, ph1, tid_t);
+    else syrk128_tile<T, true, 0, TRI, 1>(strip, g.ld, Mj, g.ldm, Cq, g.ld, SY_T * (j + 1), 0, As, Bs, false, ph0, ph1, tid_t);   // (same barriers on both paths)
     // X_j is the A operand of the next column.  Producer and consumer are the same workgroup (one CU, one L1/L2
-    // path), so workgroup scope is enough: __syncthreads() waits for this wave's stores (vmcnt) and for everyone's
-    // fragment reads of this tile before the next tile's DMA refills the LDS buffers.  (An agent-scope fence here
-    // writes back / invalidates the XCD's L2 on gfx950 and cost 10 % of the whole fit.)
+    // path), so workgroup scope is enough -- but the wait for this wave's stores has to be spelled out: a workgroup-
+    // scope fence on gfx950 (not in threadgroup-split mode) does not include vmcnt(0), and whether the compiler's own
+    // waitcnt pass puts one in front of the barrier depends on the surrounding control flow (it did for the plain tile
+    // and did not behind the two column-wave instantiations: the next column's LDS-DMA then read rows of X_j that had not
+    // landed -- wrong factors in large lockstep groups only).  Then the barrier: everyone's stores are out and everyone's
+    // fragment reads of this tile are done before the next tile's DMA refills the LDS buffers.  (An agent-scope fence
+    // here writes back / invalidates the XCD's L2 on gfx950 and cost 10 % of the whole fit.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 }

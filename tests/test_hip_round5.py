@@ -268,3 +268,36 @@ def test_bench_falls_back_to_fewer_grid_points_when_hbm_is_short():
     assert line["config"]["fits_per_step"] == 80 and line["config"]["lockstep_group_asked"] == 160, line["config"]
     assert line["value"] > 0 and line["steps"] == 1 and abs(line["value"] - 80 / (line["ms_per_step"] * 1e-3)) <= 1e-6 * line["value"]
     assert len(p.stdout.strip().splitlines()[-1]) <= 1500
+
+
+def test_strip_solve_skipping_the_zero_tile_slices_is_bit_identical(S):
+    """panel_strip_kernel multiplies a strip by [Mt_j0 .. Mt_jj]^T; Mt_jj = inv(L_jj) is lower triangular, and the `strip_tri` form
+    (default) issues only the 16-column x 16-k tile-slices of that block that are not identically zero (its column tiles interleaved
+    over the two column waves).  The skipped products are exact zeros: the factor L~ itself, nlML, sigma_f and the predictions are
+    bit-identical to the full products (`strip_tri` = 0) -- a single fit at three panel widths incl. a ragged last panel, and a
+    lockstep batch; the fit is also checked against the oracle."""
+    for n, W in ((2300, 8), (1300, 4), (1100, 2)):
+        X, y, Xs = O.synthetic_problem(n, 8, 7700 + n, m=3)
+        out = []
+        for tri in (1, 0):
+            with S.GPR(kernel="rbf", outer_blocks=W, panel_mode="strips") as gp:
+                gp.set_option("strip_tri", tri)
+                gp.fit(X, y, np.sqrt(8.0), 1e-1, Xs=Xs)
+                mu, var = gp.predict(Xs)
+                out.append((gp.nlml_, gp.sigma_f_, mu, var, gp.L_tilde_))
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1])), (n, W)
+        if n == 2300:
+            ref = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-1, kind="rbf", ref_idiom=False)
+            assert rel(out[0][2], ref["fmean"]) <= 1e-8 and rel(out[0][0], ref["nlml"]) <= 1e-10
+            assert np.max(np.abs(np.tril(out[0][4]) - ref["L_tilde"])) <= 1e-11
+    n, d, B = 1500, 8, 6
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 270 + b, m=1)
+    res = []
+    for tri in (1, 0):
+        with S.GPR(kernel="rbf", outer_blocks=8, panel_mode="strips") as gp:
+            gp.set_option("strip_tri", tri)
+            res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
+    for k in ("nlml", "mean", "var", "sigma_f"):
+        assert np.array_equal(res[0][k], res[1][k]), k
