@@ -186,6 +186,7 @@ struct sigp_handle {
   int opt_panel_mode = 2;    // rows below a panel's top block: 0 recursion (trsm + updates per 128 columns), 1 strip solve (panel_strip_kernel),
                              // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
   int opt_strip_min = 512;
+  int opt_diag_tiles = 1;    // symmetric trailing updates: a diagonal tile multiplies the 36 of 64 16 x 16 pairs on or below its diagonal (0 = the whole tile; same lower halves)
   int opt_strip_tri = 1;     // strip solves skip the zero tile-slices of the inverse diagonal blocks (0 = multiply the whole 128 x 128 block: same bits, 9 % more MFMAs)
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
@@ -469,6 +470,16 @@ int launch_syrk128_t(sigp_handle* h, hipStream_t st, const GemmArgsT<T>& g, bool
 #else
   (void)may_persist;
 #endif
+  if constexpr (!SET) {
+    // symmetric update (lower tile space over one operand): its diagonal tiles multiply their lower half only (syrk128_tile's DG form)
+    if (h->opt_diag_tiles && g.lower && g.A == g.B && g.lda == g.ldb && g.sA == g.sB && g.zA == g.zB && g.r0 <= g.c0) {
+      static AttrOnce attr_d;
+      HIPCHK(h, attr_d.set(h->device, (const void*)syrk128_kernel<T, false, false, 0, true>, SY_LDS_BYTES));
+      hipLaunchKernelGGL((syrk128_kernel<T, false, false, 0, true>), dim3(nt, std::max(1, g.batch), std::max(1, g.zcount)), dim3(256), SY_LDS_BYTES, st, g);
+      HIPCHK(h, hipGetLastError());
+      return SIGP_OK;
+    }
+  }
   hipLaunchKernelGGL((syrk128_kernel<T, SET>), dim3(nt, std::max(1, g.batch), std::max(1, g.zcount)), dim3(256), SY_LDS_BYTES, st, g);
   HIPCHK(h, hipGetLastError());
   return SIGP_OK;
@@ -482,8 +493,8 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   const double nt1 = gemm_tile_count(g.r0, g.r1, g.c0, g.c1, g.lower);
   const int nt = (int)nt1 * nb;
   if (nt <= 0) return SIGP_OK;
-  // algorithmic work: a diagonal tile of a lower (SYRK-shaped) update only needs its lower half; the kernel computes the
-  // whole tile, but the strictly-upper NB(NB-1)/2 entries are not counted as flops
+  // algorithmic work: a diagonal tile of a lower (SYRK-shaped) update only needs its lower half -- the strictly-upper NB(NB-1)/2 entries are
+  // not counted as flops (syrk128_kernel multiplies 36 of the 64 16 x 16 pairs of such a tile, the other tile kernels all of them)
   int ndiag = 0;
   if (g.lower) for (int c = g.c0; c < g.c1; ++c) ndiag += (c >= g.r0 && c < g.r1);
   const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1)) * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
@@ -1304,6 +1315,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     if (!DBG_MASK) return fail(h, SIGP_BAD_ARG, "c_dma is a measurement switch of libsigp_debug.so");
     h->opt_c_dma = value != 0; return SIGP_OK;
   }
+  if (!strcmp(name, "diag_tiles")) { h->opt_diag_tiles = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_tri")) { h->opt_strip_tri = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }

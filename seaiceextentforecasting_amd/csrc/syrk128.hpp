@@ -36,11 +36,20 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // (wave wn owns tiles wn, wn + 2, wn + 4, wn + 6 of the 128 columns instead of four consecutive ones: Cw points at column 16 wn) so that
 // both column waves of a row pair skip about the same share, and slice s' = 0 .. 7 of that K block issues the MFMAs of its tiles
 // jj >= ceil((s' - wn) / 2) only: 16 / 20 of 32 tile-slices for wn = 0 / 1.  The skipped products are exact zeros: same bits.
-template <typename T, bool SET, int ABL = 0, bool TRI = false, int WNC = 0>
+// DG (diagonal tiles of a symmetric update, C = C - A A^T with the same rows on both sides; only the lower half of such a tile is ever
+// read): BOTH the wave's four 16-row tiles and its four 16-column tiles are interleaved (row tiles wm, wm + 2, ..; column tiles wn, wn + 2, ..:
+// Cw points at row 16 wm, column 16 wn) and the wave loads, multiplies and stores only the 16 x 16 pairs on or below the diagonal:
+// DG = 1 (waves 0, 2, 3) pairs j <= i, 10 of 16; DG = 2 (wave 1: row tiles even, column tiles odd) pairs j < i, 6 of 16.  36 of 64 pairs
+// per tile; the pairs above the diagonal are left as they are in memory.  The kept pairs see the same products in the same order.
+template <typename T, bool SET, int ABL = 0, bool TRI = false, int WNC = 0, int DG = 0>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
                                              long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1,
                                              int tid_in = -1) {
   static_assert(!TRI || (SET && sizeof(T) == 8), "TRI: fp64 strip solves only (C is not read)");
+  static_assert(!DG || (!TRI && !SET), "DG: diagonal tiles of the trailing update");
+  constexpr int IS = DG ? 32 : 16;                  // rows between a wave's consecutive 16-row tiles
+  constexpr int JS = (TRI || DG) ? 32 : 16;         // columns between a wave's consecutive 16-column tiles
+#define SY_NEED(i, j) (DG == 0 || (DG == 1 ? (j) <= (i) : (j) < (i)))
   const int dbg = dbg_in & DBG_MASK;            // ablation bits: debug library only
   const bool stamp = stamp_in && DBG_MASK != 0;
   typedef Num<T> N_;
@@ -70,17 +79,19 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const acc_t c = *(const acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * 16 + 4 * lq);
+        if (!SY_NEED(i, j)) continue;
+        const acc_t c = *(const acc_t*)(Cw + (long)(i * IS + lr) * ldc + j * JS + 4 * lq);
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = -c[r];
       }
-  } else if (!(dbg & 128)) {   // accumulator-layout loads straight from global: 64 8-byte loads per lane
+  } else if (DG || !(dbg & 128)) {   // accumulator-layout loads straight from global: 64 8-byte loads per lane
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j)
+        if (SY_NEED(i, j))
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[i][j][r] = -Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * 16 + lr];
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = -Cw[(long)(i * IS + N_::drow(lq, r)) * ldc + j * JS + lr];
   } else {
     // (dbg 128) acc = -C through LDS: the C tile comes in by LDS-DMA (16 bytes per lane, one wave-instruction per 1 KiB)
     // in two halves of 64 rows -- the A/B staging buffers are idle before the K loop -- and each wave picks its
@@ -134,8 +145,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   // fragment read offsets (elements) inside a row for k-group h = 0 / 1
   const int x = (lr >> 1) & 7;
   const int fo0 = ((lq ^ x) & 7) * NE, fo1 = (((4 + lq) ^ x) & 7) * NE;
-  constexpr int JS = TRI ? 32 : 16;                 // columns between a wave's consecutive 16-column tiles
-  const int arow0 = (wm * 64 + lr) * KTe, brow0 = ((TRI ? wn * 16 : wn * 64) + lr) * KTe;
+  const int arow0 = ((DG ? wm * 16 : wm * 64) + lr) * KTe, brow0 = ((TRI || DG ? wn * 16 : wn * 64) + lr) * KTe;
 
   // Software pipeline (2 LDS buffers, one barrier per K-slice, placed MID-slice):
   //   MFMA group 0 with the 8 group-1 fragment reads of slice s spread through it | barrier (slice s+1 landed, slice s fully read)
@@ -150,7 +160,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   if (stamp) ph0 = __builtin_amdgcn_s_memtime();   // C tile and first K-slice have landed
   if (nst > 1) SY_ISSUE(KTe, 1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * 16 * KTe + fo0);
+  for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(As + arow0 + i * IS * KTe + fo0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bs + brow0 + j * JS * KTe + fo0);
   // The loads sit INSIDE the MFMA groups (sched_group_barrier recipes: one load, G/8 MFMAs, ...).  The DMA is unconditional inside the
@@ -159,13 +169,13 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   // and the debug library's ABL = 0 kernel are the same code.
   auto slice = [&](int s, auto with_dma, auto jmin_c) __attribute__((always_inline)) {
     constexpr int JMIN = decltype(jmin_c)::value;       // first 16-column tile of the wave this slice multiplies (0 unless TRI)
-    constexpr int NM = NE * 4 * (4 - JMIN);             // MFMAs per group
+    constexpr int NM = NE * (DG == 1 ? 10 : DG == 2 ? 6 : 4 * (4 - JMIN));   // MFMAs per group
     constexpr int NP = NM < 8 ? NM : 8;                 // ... of which this many lead one load each
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
     const T* Bb = Bs + buf * SY_T * KTe + brow0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * 16 * KTe + fo1);
+    for (int i = 0; i < 4; ++i) a1[i] = *(const v16_t*)(Ab + i * IS * KTe + fo1);
 #pragma unroll
     for (int j = 0; j < 4; ++j) b1[j] = *(const v16_t*)(Bb + j * JS * KTe + fo1);
     if (!(ABL & 4))
@@ -174,7 +184,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = JMIN; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
+        for (int j = JMIN; j < 4; ++j)
+          if (SY_NEED(i, j)) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b0[j][e], a0[i][e], acc[i][j]) : N_::mfma(a0[i][e], b0[j][e], acc[i][j]);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {                      // reads early, one per MFMA (the first MFMA leads: its operands' wait -- lgkmcnt(0) --
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // would otherwise wait for the first of these reads as well), then the rest of the group
@@ -190,7 +201,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
       const T* An = As + (buf ^ 1) * SY_T * KTe + arow0;
       const T* Bn = Bs + (buf ^ 1) * SY_T * KTe + brow0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(An + i * 16 * KTe + fo0);
+      for (int i = 0; i < 4; ++i) a0[i] = *(const v16_t*)(An + i * IS * KTe + fo0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) b0[j] = *(const v16_t*)(Bn + j * JS * KTe + fo0);
     }
@@ -200,7 +211,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = JMIN; j < 4; ++j) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
+        for (int j = JMIN; j < 4; ++j)
+          if (SY_NEED(i, j)) acc[i][j] = TRANSPOSED_ACC ? N_::mfma(b1[j][e], a1[i][e], acc[i][j]) : N_::mfma(a1[i][e], b1[j][e], acc[i][j]);
     if (decltype(with_dma)::value && NM >= 16) {
       // the DMA first (it is waited for one group + one barrier later: every MFMA it is issued behind comes off its lead), then the reads
 #pragma unroll
@@ -214,6 +226,14 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
       }
       if (NM > 16) __builtin_amdgcn_sched_group_barrier(0x008, NM - 16, 1);
+    } else if (decltype(with_dma)::value && NM >= 8) {   // short groups (the six-pair diagonal wave): the DMA behind the first MFMAs, then the reads
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 1);
+      if (NM > 8) __builtin_amdgcn_sched_group_barrier(0x008, NM - 8, 1);
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -242,21 +262,26 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if (!SY_NEED(i, j)) continue;
         if (TRANSPOSED_ACC) {
           acc_t c;
 #pragma unroll
           for (int r = 0; r < 4; ++r) c[r] = SET ? acc[i][j][r] : -acc[i][j][r];
-          *(acc_t*)(Cw + (long)(i * 16 + lr) * ldc + j * JS + 4 * lq) = c;
+          *(acc_t*)(Cw + (long)(i * IS + lr) * ldc + j * JS + 4 * lq) = c;
         } else {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) Cw[(long)(i * 16 + N_::drow(lq, r)) * ldc + j * JS + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
+          for (int r = 0; r < 4; ++r) Cw[(long)(i * IS + N_::drow(lq, r)) * ldc + j * JS + lr] = SET ? acc[i][j][r] : -acc[i][j][r];
         }
       }
   }
+#undef SY_NEED
 }
 
-template <typename T, bool SET, bool PERSIST = false, int ABL = 0>
+// DIAG_SKIP: the launch is a symmetric update (lower tile space, same operand on both sides) and its diagonal tiles take the DG form of
+// the tile -- 36 of the 64 16 x 16 pairs (launch_syrk128_t picks the instantiation).
+template <typename T, bool SET, bool PERSIST = false, int ABL = 0, bool DIAG_SKIP = false>
 __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
+  static_assert(!DIAG_SKIP || (!SET && !PERSIST && ABL == 0), "DIAG_SKIP: the product trailing update only");
   constexpr int KTe = Num<T>::KT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* As = (T*)smem_raw;                 // [2][128][KT]
@@ -287,13 +312,21 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     int K = g.K;
     if (g.ktri == 1) { const int ks = bi * SY_T; Ag += ks; Bg += ks; K -= ks; }   // upper-triangular operand rows: nothing left of the diagonal block
     T* Cw = g.C + bz * g.sC + zz * g.zC + ((long)bi * SY_T + wm * 64) * g.ldc + (long)bj * SY_T + wn * 64;
+    // diagonal tile of a symmetric update (same rows of the same matrix on both sides): only its lower half is ever read
+    const bool diag = DIAG_SKIP && g.lower && bi == bj && g.A == g.B && g.sA == g.sB && g.zA == g.zB && g.lda == g.ldb;
     unsigned long long st_c0 = 0, st_r0 = 0;
     if (stamp) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     unsigned long long ph0 = 0, ph1 = 0;
     int tid_t = tid;
-    if (PERSIST) asm volatile("" : "+v"(tid_t));   // opaque per tile: keeps the lane-dependent address arithmetic of the tile inside the
+    if (PERSIST || DIAG_SKIP) asm volatile("" : "+v"(tid_t));   // opaque per tile: keeps the lane-dependent address arithmetic of the tile inside the
                                                    // loop (hoisted, it costs 18 VGPRs that do not exist: the kernel would spill to scratch)
-    syrk128_tile<T, SET, ABL>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+    if (DIAG_SKIP && diag) {
+      T* Cd = g.C + bz * g.sC + zz * g.zC + ((long)bi * SY_T + wm * 16) * g.ldc + (long)bj * SY_T + wn * 16;
+      if (wave == 1) syrk128_tile<T, SET, ABL, false, 0, DIAG_SKIP ? 2 : 0>(Ag, g.lda, Bg, g.ldb, Cd, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+      else syrk128_tile<T, SET, ABL, false, 0, DIAG_SKIP ? 1 : 0>(Ag, g.lda, Bg, g.ldb, Cd, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+    } else {
+      syrk128_tile<T, SET, ABL>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+    }
     if (stamp && (g.dbg & 256)) {   // phase breakdown: wait for the C stores, then {prologue, loop, epilogue} cycles of wave 0
       __builtin_amdgcn_s_waitcnt(0);
       if (tid == 0) {

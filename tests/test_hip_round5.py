@@ -301,3 +301,43 @@ def test_strip_solve_skipping_the_zero_tile_slices_is_bit_identical(S):
             res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
     for k in ("nlml", "mean", "var", "sigma_f"):
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_diagonal_tiles_of_the_trailing_update_lower_half_only(S, dtype):
+    """A diagonal 128 x 128 tile of the symmetric trailing update is only ever read below its diagonal: `diag_tiles` (default on) lets
+    `syrk128_kernel` load, multiply and store the 36 of its 64 16 x 16 sub-tile pairs on or below the diagonal (row AND column tiles of a
+    wave interleaved so that the four waves keep 10 / 6 / 10 / 10 pairs).  Kept pairs see the same products in the same order: L~, nlML,
+    sigma_f and the predictions are bit-identical to the full tiles -- single fits at sizes that reach the 128-tile update kernel
+    (more than small_tile_threshold tiles), a ragged one, both schedules, and a lockstep batch."""
+    kern = "rbf" if dtype == "f64" else "matern52"
+    for n, W, sched in ((4100, 8, 0), (3500, 4, 1), (2300, 8, 0)):
+        X, y, Xs = O.synthetic_problem(n, 8, 8800 + n, m=2)
+        out = []
+        for on in (1, 0):
+            with S.GPR(kernel=kern, outer_blocks=W, dtype=dtype) as gp:
+                gp.set_option("diag_tiles", on)
+                gp.set_option("schedule", sched)
+                gp.set_option("small_tile_threshold", 1)          # every trailing update on the 128-tile kernel
+                gp.set_option("tiny_tile_threshold", 1)
+                gp.fit(X, y, np.sqrt(8.0), 1e-1, Xs=Xs)
+                mu, var = gp.predict(Xs)
+                out.append((gp.nlml_, gp.sigma_f_, mu, var) + ((gp.L_tilde_,) if dtype == "f64" else ()))
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1])), (n, W)
+        if n == 4100 and dtype == "f64":
+            ref = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-1, kind="rbf", ref_idiom=False)
+            assert rel(out[0][2], ref["fmean"]) <= 1e-8 and rel(out[0][0], ref["nlml"]) <= 1e-10
+            assert np.max(np.abs(out[0][4] - ref["L_tilde"])) <= 1e-11
+    if dtype == "f32":
+        return
+    n, d, B = 2100, 8, 6
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 1, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 370 + b, m=1)
+    res = []
+    for on in (1, 0):
+        with S.GPR(kernel="rbf", outer_blocks=4) as gp:
+            gp.set_option("diag_tiles", on)
+            res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
+    for k in ("nlml", "mean", "var", "sigma_f"):
+        assert np.array_equal(res[0][k], res[1][k]), k
