@@ -286,6 +286,8 @@ int sigp_synchronize(sigp_handle* h);
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]
  *   diag_tiles [1]        symmetric trailing updates: a diagonal 128 x 128 tile loads, multiplies and stores only the 36 of its 64 16 x 16 pairs on or below
  *                         the diagonal (nothing reads the rest; same lower halves bit for bit; 0 = whole tiles, for A/B timing)
+ *   ride_tiles [1]        trailing updates: while at most 16 rows of the ride-along block are in use (y and up to 15 test points), its tiles stage and
+ *                         multiply those 16 rows only (the other rows are zero rows; same results bit for bit; 0 = whole tiles, for A/B timing)
  *   strip_tri [1]         strip solves skip the zero 16-column x 16-k tile-slices of the inverse diagonal blocks (same bits; 0 = the full products, for A/B timing)
  *   group [8]             fits factorised in lockstep per launch (batch path, fp64 and fp32; 1..256)
  *   small_tile_threshold [320], tiny_tile_threshold [256], trsm128_threshold [256]   tile-shape switches by tile count

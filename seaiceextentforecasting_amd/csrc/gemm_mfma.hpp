@@ -82,6 +82,9 @@ struct GemmArgsT {
   int zcount; long zA, zB, zC; // a second batch dimension (grid.z, strides in elements): lockstep members x (pairs of a level | panels)
   int zshift;                  // lower, plain walk, batched: member z's trapezoid starts zshift*z rows lower (rows bi >= bj + zshift*z) -- the
                                // block-cyclic column panels one rank owns in a sharded factor, updated in ONE launch (grid.y = own panel)
+  int ride_bi1;                // syrk128_kernel (symmetric updates): 1 + the block row that is the ride-along block with at most 16 rows in use
+                               // (its tiles take the RD form: 8 of 64 sub-tile pairs); 0 = no such row.  ride_rows = the rows in use (accounting)
+  int ride_rows;
 };
 typedef GemmArgsT<double> GemmArgs;
 

@@ -187,6 +187,7 @@ struct sigp_handle {
                              // 2 strips when there are at least opt_strip_min strips x members to fill the chip (lockstep batches)
   int opt_strip_min = 512;
   int opt_diag_tiles = 1;    // symmetric trailing updates: a diagonal tile multiplies the 36 of 64 16 x 16 pairs on or below its diagonal (0 = the whole tile; same lower halves)
+  int opt_ride_tiles = 1;    // trailing updates: tiles of the ride-along block row multiply its first 16 rows only when no more are in use (y + <= 15 test points)
   int opt_strip_tri = 1;     // strip solves skip the zero tile-slices of the inverse diagonal blocks (0 = multiply the whole 128 x 128 block: same bits, 9 % more MFMAs)
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
@@ -497,7 +498,10 @@ int gemm_sub_auto(sigp_handle* h, hipStream_t st, GemmArgsT<T> g /* in 128-units
   // not counted as flops (syrk128_kernel multiplies 36 of the 64 16 x 16 pairs of such a tile, the other tile kernels all of them)
   int ndiag = 0;
   if (g.lower) for (int c = g.c0; c < g.c1; ++c) ndiag += (c >= g.r0 && c < g.r1);
-  const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1)) * g.K, bytes = nt1 * nb * 2.0 * NB * NB * sizeof(T);
+  int nride = 0;             // ... and a tile of a ride-along block row with ride_rows <= 16 rows in use counts those rows only
+  if (g.ride_bi1 > 0 && g.ride_bi1 - 1 >= g.r0 && g.ride_bi1 - 1 < g.r1) nride = g.c1 - g.c0;
+  const double flops = nb * (nt1 * 2.0 * NB * NB - ndiag * (double)NB * (NB - 1) - nride * 2.0 * NB * (NB - g.ride_rows)) * g.K,
+               bytes = nb * (nt1 * 2.0 * NB * NB - nride * 2.0 * NB * (NB - g.ride_rows)) * sizeof(T);
   if (nt >= h->opt_small_tiles && (h->opt_syrk_v2 || sizeof(T) == 4)) {
     ProfScope ps(h, st, SIGP_KC_SYRK128, flops, bytes, g.K);
 #ifdef SIGP_DEBUG_TOOLS
@@ -722,10 +726,14 @@ inline int outer_width(const sigp_handle* h, int nb, int T, bool f32 = false) {
   return (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
 }
 template <typename Real>
-int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad, bool head_on_panel = false) {
+int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad, bool head_on_panel = false,
+               int ride_rows = RIDE) {
   const long ld = n_pad;
   const int T = (int)(n_pad / NB);   // column blocks
   const int R = T + 1;               // row blocks including the ride block
+  // ride_rows: rows of the ride-along block in use (y + the test points; the rest are zero rows).  Up to 16: the block row's tiles in the
+  // trailing updates multiply their first 16-row sub-tile only (syrk128_tile's RD form)
+  const bool ride16 = h->opt_ride_tiles && ride_rows <= 16;
   const int W = outer_width(h, nb, T, std::is_same<Real, float>::value);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
@@ -756,6 +764,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
     g.C = M + o * ld + o; g.ldc = ld;
     g.batch = nb; g.sA = g.sB = g.sC = matStride;
     g.K = kw * NB; g.r0 = 0; g.r1 = rlim - ccol0; g.c0 = c0; g.c1 = c1; g.lower = 1; g.patch = h->opt_patch;
+    if (ride16 && rlim == R) { g.ride_bi1 = R - ccol0; g.ride_rows = ride_rows; }     // (block row R - 1 of the matrix = row R - 1 - ccol0 of this tile space)
     return g;
   };
   auto update = [&](hipStream_t st, int kclass, int kcol0, int kw, int ccol0, int c0, int c1, int rlim) -> int {
@@ -1008,8 +1017,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   return SIGP_OK;
 }
 
-int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad, bool head_on_panel = false) {
-  return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad, head_on_panel);
+int potrf_slot(sigp_handle* h, Slot& s, int nb, long n_pad, bool head_on_panel = false, int ride_rows = RIDE) {
+  return potrf_core<double>(h, s, s.mat, s.matStride, s.dinv, s.dinvStride, nb, n_pad, head_on_panel, ride_rows);
 }
 
 // stand-alone pieces of potrf_core for the multi-GPU driver (one member; Mm / dinvp = the fp64 slot matrix or the fp32 engine's)
@@ -1316,6 +1325,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
     h->opt_c_dma = value != 0; return SIGP_OK;
   }
   if (!strcmp(name, "diag_tiles")) { h->opt_diag_tiles = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "ride_tiles")) { h->opt_ride_tiles = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_tri")) { h->opt_strip_tri = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
@@ -1559,7 +1569,7 @@ int sigp_potrf(sigp_handle* h, int64_t* info) {
   if (!h || !h->built) return fail(h, SIGP_BAD_ARG, "potrf: build the kernel matrix first");
   HIPCHK(h, hipSetDevice(h->device));
   Slot& s = h->slots[0];
-  int rc = potrf_slot(h, s, 1, h->n_pad);
+  int rc = potrf_slot(h, s, 1, h->n_pad, false, 1 + (int)h->m);
   if (rc) return rc;
   HIPCHK(h, hipMemcpyAsync(s.info_host, s.info, sizeof(int), hipMemcpyDeviceToHost, s.s_upd));
   rc = sync_slot(h, s);
@@ -1633,7 +1643,7 @@ int sigp_fit_predict(sigp_handle* h, int kernel_id, double ell, double sn_tilde,
     rc = build_cov(h, s, 1, h->X, 0, h->y, 0, h->Xs, 0, h->n, h->d, h->dp, h->n_pad, h->m);
     if (rc) return rc;
   }
-  if ((rc = potrf_slot(h, s, 1, h->n_pad))) return rc;
+  if ((rc = potrf_slot(h, s, 1, h->n_pad, false, 1 + (int)h->m))) return rc;
   if ((rc = epilogue_slot(h, s, 1, h->n, h->n_pad, h->m))) return rc;
   if ((rc = sync_slot(h, s))) return rc;
   const int info = *s.info_host;
@@ -1951,7 +1961,7 @@ int sigp_batch_run(sigp_handle* h, int64_t first, int64_t count, int kernel_id, 
     if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, m, sb))) return rc;
     // pipeline_head = 2: only the covariance build (HBM / VALU work) runs under the previous group; the first panel waits too
     if (head && h->opt_pipeline_head == 2 && g > 0) HIPCHK(h, hipStreamWaitEvent(s.s_pan, h->slots[(g - 1) % nslots].ev_group, 0));
-    if ((rc = potrf_slot(h, s, nb, n_pad, head))) return rc;
+    if ((rc = potrf_slot(h, s, nb, n_pad, head, 1 + (int)m))) return rc;
     if ((rc = epilogue_slot(h, s, nb, n, n_pad, m))) return rc;
     if (head) HIPCHK(h, hipEventRecord(s.ev_group, s.s_upd));
     inflight[k] = g;
@@ -2121,7 +2131,7 @@ int sigp_nlml_grad_batch(sigp_handle* h, int64_t first, int64_t count, int kerne
     }
     if ((rc = upload_kparams(h, s, nb))) return rc;
     if ((rc = build_cov(h, s, nb, h->bX, n_pad * dp, h->by, n_pad, h->bXs, (long)RIDE * dp, n, d, dp, n_pad, 0))) return rc;
-    if ((rc = potrf_slot(h, s, nb, n_pad))) return rc;
+    if ((rc = potrf_slot(h, s, nb, n_pad, false, 1))) return rc;
     if ((rc = epilogue_slot(h, s, nb, n, n_pad, 0))) return rc;
     if (grad_mode != 0) {
       // U = L~^-T for every member at once, P parks in gK

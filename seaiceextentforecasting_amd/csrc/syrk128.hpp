@@ -41,7 +41,10 @@ typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
 // Cw points at row 16 wm, column 16 wn) and the wave loads, multiplies and stores only the 16 x 16 pairs on or below the diagonal:
 // DG = 1 (waves 0, 2, 3) pairs j <= i, 10 of 16; DG = 2 (wave 1: row tiles even, column tiles odd) pairs j < i, 6 of 16.  36 of 64 pairs
 // per tile; the pairs above the diagonal are left as they are in memory.  The kept pairs see the same products in the same order.
-template <typename T, bool SET, int ABL = 0, bool TRI = false, int WNC = 0, int DG = 0>
+// RD (tiles of the ride-along block row when at most 16 of its 128 rows are in use -- y and up to 15 test points; the rest are zero rows):
+// only the first 16-row tile takes part.  RD = 1 (the row waves wm = 0): pairs i = 0, and of A only rows 0 .. 15 are staged; RD = 2 (wm = 1):
+// no pairs, no A rows -- the wave stages its share of B and keeps the barriers.  Rows 16 .. 127 of C are neither read nor written.
+template <typename T, bool SET, int ABL = 0, bool TRI = false, int WNC = 0, int DG = 0, int RD = 0>
 __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg, long ldb, T* Cw,
                                              long ldc, int K, int dbg_in, T* As, T* Bs, bool stamp_in, unsigned long long& ph0, unsigned long long& ph1,
                                              int tid_in = -1) {
@@ -49,7 +52,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   static_assert(!DG || (!TRI && !SET), "DG: diagonal tiles of the trailing update");
   constexpr int IS = DG ? 32 : 16;                  // rows between a wave's consecutive 16-row tiles
   constexpr int JS = (TRI || DG) ? 32 : 16;         // columns between a wave's consecutive 16-column tiles
-#define SY_NEED(i, j) (DG == 0 || (DG == 1 ? (j) <= (i) : (j) < (i)))
+  static_assert(!RD || (!TRI && !SET && !DG), "RD: ride-row tiles of the trailing update");
+#define SY_NEED(i, j) (RD ? (RD == 1 && (i) == 0) : (DG == 0 || (DG == 1 ? (j) <= (i) : (j) < (i))))
   const int dbg = dbg_in & DBG_MASK;            // ablation bits: debug library only
   const bool stamp = stamp_in && DBG_MASK != 0;
   typedef Num<T> N_;
@@ -135,8 +139,9 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 #define SY_ISSUE(k0, buf)                                                                                     \
   {                                                                                                           \
     _Pragma("unroll") for (int p = 0; p < 4; ++p) {                                                           \
-      __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Asrc + p * a32 + (k0)),                                    \
-                                       (lds_ptr_t)(As + ((buf) * SY_T + p * 32 + wave * 8) * KTe), 16, 0, 0); \
+      if (RD == 0 || (RD == 1 && p == 0))                                                                     \
+        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Asrc + p * a32 + (k0)),                                  \
+                                         (lds_ptr_t)(As + ((buf) * SY_T + p * 32 + wave * 8) * KTe), 16, 0, 0); \
       __builtin_amdgcn_global_load_lds((gbl_ptr_t)(Bsrc + p * b32 + (k0)),                                    \
                                        (lds_ptr_t)(Bs + ((buf) * SY_T + p * 32 + wave * 8) * KTe), 16, 0, 0); \
     }                                                                                                         \
@@ -169,7 +174,7 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
   // and the debug library's ABL = 0 kernel are the same code.
   auto slice = [&](int s, auto with_dma, auto jmin_c) __attribute__((always_inline)) {
     constexpr int JMIN = decltype(jmin_c)::value;       // first 16-column tile of the wave this slice multiplies (0 unless TRI)
-    constexpr int NM = NE * (DG == 1 ? 10 : DG == 2 ? 6 : 4 * (4 - JMIN));   // MFMAs per group
+    constexpr int NM = NE * (RD == 1 ? 4 : RD == 2 ? 0 : DG == 1 ? 10 : DG == 2 ? 6 : 4 * (4 - JMIN));   // MFMAs per group
     constexpr int NP = NM < 8 ? NM : 8;                 // ... of which this many lead one load each
     const int buf = s & 1;
     const T* Ab = As + buf * SY_T * KTe + arow0;
@@ -278,7 +283,8 @@ __device__ __forceinline__ void syrk128_tile(const T* Ag, long lda, const T* Bg,
 }
 
 // DIAG_SKIP: the launch is a symmetric update (lower tile space, same operand on both sides) and its diagonal tiles take the DG form of
-// the tile -- 36 of the 64 16 x 16 pairs (launch_syrk128_t picks the instantiation).
+// the tile -- 36 of the 64 16 x 16 pairs (launch_syrk128_t picks the instantiation); the tiles of block row g.ride_bi1 - 1 (the ride-along
+// block, when at most 16 of its rows are in use) take the RD form -- 8 of 64 pairs.
 template <typename T, bool SET, bool PERSIST = false, int ABL = 0, bool DIAG_SKIP = false>
 __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
   static_assert(!DIAG_SKIP || (!SET && !PERSIST && ABL == 0), "DIAG_SKIP: the product trailing update only");
@@ -320,7 +326,11 @@ __global__ __launch_bounds__(256, 2) void syrk128_kernel(GemmArgsT<T> g) {
     int tid_t = tid;
     if (PERSIST || DIAG_SKIP) asm volatile("" : "+v"(tid_t));   // opaque per tile: keeps the lane-dependent address arithmetic of the tile inside the
                                                    // loop (hoisted, it costs 18 VGPRs that do not exist: the kernel would spill to scratch)
-    if (DIAG_SKIP && diag) {
+    const bool ride = DIAG_SKIP && g.ride_bi1 > 0 && bi == g.ride_bi1 - 1;      // ride-along block row with at most 16 rows in use
+    if (DIAG_SKIP && ride) {
+      if (wm == 0) syrk128_tile<T, SET, ABL, false, 0, 0, DIAG_SKIP ? 1 : 0>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+      else syrk128_tile<T, SET, ABL, false, 0, 0, DIAG_SKIP ? 2 : 0>(Ag, g.lda, Bg, g.ldb, Cw, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
+    } else if (DIAG_SKIP && diag) {
       T* Cd = g.C + bz * g.sC + zz * g.zC + ((long)bi * SY_T + wm * 16) * g.ldc + (long)bj * SY_T + wn * 16;
       if (wave == 1) syrk128_tile<T, SET, ABL, false, 0, DIAG_SKIP ? 2 : 0>(Ag, g.lda, Bg, g.ldb, Cd, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);
       else syrk128_tile<T, SET, ABL, false, 0, DIAG_SKIP ? 1 : 0>(Ag, g.lda, Bg, g.ldb, Cd, g.ldc, K, g.dbg, As, Bs, stamp != nullptr, ph0, ph1, tid_t);

@@ -341,3 +341,46 @@ def test_diagonal_tiles_of_the_trailing_update_lower_half_only(S, dtype):
             res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
     for k in ("nlml", "mean", "var", "sigma_f"):
         assert np.array_equal(res[0][k], res[1][k]), k
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_ride_along_tiles_multiply_only_the_rows_in_use(S, dtype):
+    """The ride-along block is 128 rows of which 1 + m are in use (y and the test points of north/June1st.py:272; the rest are zero rows).
+    With at most 16 in use (`ride_tiles`, default on) its tiles in the trailing updates stage and multiply the first 16-row sub-tile only.
+    Same results bit for bit as whole tiles (`ride_tiles` = 0) for m = 1, 3 and 15; m = 16 (17 rows) takes whole tiles either way; all
+    against the oracle.  Lockstep batch included."""
+    kern = "rbf" if dtype == "f64" else "matern52"
+    n, W = 3300, 8
+    for m in (1, 3, 15, 16):
+        X, y, Xs = O.synthetic_problem(n, 8, 9900 + m, m=m)
+        out = []
+        for on in (1, 0):
+            with S.GPR(kernel=kern, outer_blocks=W, dtype=dtype) as gp:
+                gp.set_option("ride_tiles", on)
+                gp.set_option("small_tile_threshold", 1)
+                gp.set_option("tiny_tile_threshold", 1)
+                if dtype == "f32" and m > 3:
+                    break                                   # (the fp32 engine refines at most 3 ride-along points)
+                gp.fit(X, y, np.sqrt(8.0), 1e-1, Xs=Xs)
+                mu, var = gp.predict(Xs)
+                out.append((gp.nlml_, gp.sigma_f_, mu, var))
+        if not out:
+            continue
+        assert all(np.array_equal(a, b) for a, b in zip(out[0], out[1])), m
+        ref = O.fit_predict(X, y, Xs, np.sqrt(8.0), 1e-1, kind=kern, ref_idiom=False)
+        tol = 1e-8 if dtype == "f64" else 1e-6
+        assert rel(out[0][2], ref["fmean"]) <= tol and rel(out[0][3], ref["fvar"]) <= (tol if dtype == "f64" else 1e-5), m
+    if dtype == "f32":
+        return
+    n, d, B = 2100, 8, 6
+    Xb = np.zeros((B, n, d)); yb = np.zeros((B, n)); Xsb = np.zeros((B, 2, d))
+    for b in range(B):
+        Xb[b], yb[b], Xsb[b] = O.synthetic_problem(n, d, 470 + b, m=2)
+    res = []
+    for on in (1, 0):
+        with S.GPR(kernel="rbf", outer_blocks=4) as gp:
+            gp.set_option("ride_tiles", on)
+            gp.set_option("small_tile_threshold", 1)
+            res.append(gp.fit_batch(Xb, yb, Xsb, np.full(B, 2.5), np.logspace(-2, -1, B), concurrency=1, group=B))
+    for k in ("nlml", "mean", "var", "sigma_f"):
+        assert np.array_equal(res[0][k], res[1][k]), k
