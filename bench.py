@@ -296,12 +296,13 @@ def main():
                                "achieved": ach, "peak": PEAK_F64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_MFMA_TFLOPS,
                                "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["ms"] / dom["launches"],
                                "flops_per_launch": dom["flops"] / dom["launches"],
-                               "flops_note": "algorithmic: 2*128*128*K per off-diagonal tile, the lower half (128*129*K) per diagonal tile"}
+                               "flops_note": "algorithmic: 2*128*128*K per off-diagonal tile, the lower half (128*129*K) per diagonal tile, 2*(1+m)*128*K per tile of the "
+                                             "ride-along block row (its rows in use; up to round 4 those tiles were counted -- and multiplied -- whole: x 1.049 for that accounting)"}
             quote_pmc_traffic(out["roofline"], dom, n, d, args)
         else:
             out["roofline"] = None
         if not args.no_profile:
-            X_.untimed_kernel_records(ctx, out, prof)              # per-kernel table, the kernel's unshared rate, m = 64
+            X_.untimed_kernel_records(ctx, out, prof)              # per-kernel table, the kernel's rate with the strips beside it, m = 64
     gp.close()
 
     if rank == 0 and world == 1 and not args.no_extras:
@@ -367,8 +368,8 @@ def compact_line(out):
     if rf:
         c["roofline"] = {"bound": rf["bound"], "kernel": "syrk128_kernel<double> (trailing update, v_mfma_f64_16x16x4_f64)", "achieved": round(rf["achieved"], 3), "peak": rf["peak"],
                          "unit": rf["unit"], "frac": round(rf["frac"], 4), "traffic": rf.get("traffic"), "avg_launch_ms": round(rf["avg_launch_ms"], 4), "launches": rf["launches"]}
-        if rf.get("unshared"):
-            c["roofline"]["unshared_frac"] = round(rf["unshared"]["frac"], 4)
+        if rf.get("strips_beside_update"):
+            c["roofline"]["strips_beside_update_frac"] = round(rf["strips_beside_update"]["frac"], 4)
     else:
         c["roofline"] = None
     cb = out.get("cpu_baseline")

@@ -312,8 +312,9 @@ int sigp_synchronize(sigp_handle* h);
  *   dist_timeout_ms [120000] deadline (time WITHOUT progress of the update stream's panel counter) of every host-side wait of the sharded path; RCCL's asynchronous error state is polled meanwhile.  On an
  *                         error / when it passes: ncclCommAbort, SIGP_HIP_ERROR (the panel reached is in sigp_last_error), the handle's sharded
  *                         state is dead until sigp_dist_shutdown + a fresh sigp_dist_init* -- a dead peer is an error, not a hang; 0 = wait for ever
- *   strips_after_update [0] (look-ahead: the next panel's strip solve waits for the whole trailing update instead of running beside it:
- *   the trailing-update kernel's own rate, bench.py's roofline.unshared)
+ *   strips_after_update [1] (look-ahead: the next panel's strip solve -- MFMA work for the whole chip -- waits for the rest of the trailing update; 0 = beside
+ *   it: same throughput, a batch is bound by the sum of its MFMA work, but the update's launches then last as long as both kernels' work: bench.py's
+ *   roofline.strips_beside_update)
  *   schedules of the latency chain -- bit-identical results, DESIGN.md section 7:  panel_chain [15] (bit 0: panels that are not strip-solved,
  *   bit 1: top blocks of strip-solved panels, are factored column by column with update work riding in the diagonal-block launches;
  *   bit 2: ONE launch between two diagonal blocks (chain_link_kernel: what the next block needs, the column solve riding, every other update

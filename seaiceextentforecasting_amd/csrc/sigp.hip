@@ -213,7 +213,7 @@ struct sigp_handle {
                                      // bit 3: the binary recursion's leaf pairs (two columns) take that form too
   int opt_chain_rows = 80;           // (see panel_any)
   int opt_link_rows = 256;           // fused chain link while rows-below x members stays under this (chain_panel)
-  int opt_strips_after_update = 0;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
+  int opt_strips_after_update = 1;   // right-looking schedule with look-ahead: the next panel's strip solve waits for the rest of the trailing update
   int opt_head_gate = 16;    // pipeline_head = 3: a group's tail begins when at most this many block columns remain behind the panel just enqueued
   int opt_pipeline_head = 0; // lockstep batches with >= 2 groups in flight: only the next group's head (build + first panel) overlaps the current
                              // group (measured: 312 vs 318 fits/s with one group in flight, 323 with two unrestricted -- DESIGN section 7)

@@ -45,7 +45,11 @@ A("| `roofline`: `syrk128_kernel<double>` by HIP events over the timed region | 
   % (rf["frac"], rf["achieved"], rf["launches"], rf["avg_launch_ms"], rf["flops_per_launch"]))
 c, a = stat("syrk128_kernel<double, false, false")
 A("| the same kernel in `rocprofv3 --kernel-trace --stats` of the same command | %d calls, avg %.3f ms (%.1f %% from the HIP-event average) | `profiles/%s_rocprofv3_kernel_stats.csv` |" % (c, a, 100 * abs(a - rf["avg_launch_ms"]) / rf["avg_launch_ms"], R))
-A("| ... when the strip solve does not share the chip with it (`roofline.unshared`) | %.3f (%.1f TFLOP/s) | `roofline.unshared` |" % (rf["unshared"]["frac"], rf["unshared"]["achieved"]))
+if rf.get("strips_beside_update"):
+    A("| ... with the strip solve beside the trailing update (`strips_after_update` = 0, the default up to r4) | %.3f (%.1f TFLOP/s), %.1f fits/s | `roofline.strips_beside_update` |"
+      % (rf["strips_beside_update"]["frac"], rf["strips_beside_update"]["achieved"], rf["strips_beside_update"]["fits_per_s_with_this_schedule"]))
+elif rf.get("unshared"):
+    A("| ... when the strip solve does not share the chip with it (`roofline.unshared`) | %.3f (%.1f TFLOP/s) | `roofline.unshared` |" % (rf["unshared"]["frac"], rf["unshared"]["achieved"]))
 A("| HBM-side traffic of that kernel per launch (PMC, separate passes) | %.2f GB fetched (FETCH_SIZE x 2) + %.2f GB written = **%.2f GB**; algorithmic C bytes %.2f GB; matrix pipe busy %.3f | `profiles/%s_pmc_syrk128.json` |"
   % (pm["fetch_bytes_per_launch_corrected"] / 1e9, pm["write_bytes_per_launch"] / 1e9, pm["traffic_bytes_per_launch"] / 1e9, rf.get("algorithmic_c_bytes_per_launch", 0) / 1e9, pm["mfma_pipe_busy_fraction"], R))
 cb = v["cpu_baseline"]
