@@ -10,10 +10,12 @@ kb = json.load(open(P("pmc_kbuild.json")))
 f32 = json.load(open(P("pmc_syrk128_f32.json")))
 stats = {r["Name"]: r for r in csv.DictReader(open(P("rocprofv3_kernel_stats.csv")))}
 def stat(prefix):
+    """calls and average ms over EVERY instantiation whose name contains `prefix` (the trailing update is two: with and without the diagonal / ride tile forms)"""
+    calls, tot = 0, 0.0
     for k, r in stats.items():
         if prefix in k:
-            return int(r["Calls"]), float(r["AverageNs"]) / 1e6
-    return 0, float("nan")
+            calls += int(r["Calls"]); tot += int(r["Calls"]) * float(r["AverageNs"]) / 1e6
+    return (calls, tot / calls) if calls else (0, float("nan"))
 rf = v["roofline"]
 oc = v["other_configs"]
 def trace(name):
