@@ -733,7 +733,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const int R = T + 1;               // row blocks including the ride block
   // ride_rows: rows of the ride-along block in use (y + the test points; the rest are zero rows).  Up to 16: the block row's tiles in the
   // trailing updates multiply their first 16-row sub-tile only (syrk128_tile's RD form)
-  const bool ride16 = h->opt_ride_tiles && ride_rows <= 16;
+  const bool ride16 = h->opt_ride_tiles && h->opt_diag_tiles && ride_rows <= 16;     // (the RD form lives in the kernel instantiation that has the DG form)
   const int W = outer_width(h, nb, T, std::is_same<Real, float>::value);
   constexpr int diag_lds = diag_lds_bytes<Real>();
   if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {

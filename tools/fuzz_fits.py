@@ -15,13 +15,16 @@ def run(cases, seed, verbose=True):
   fails = 0
   for case in range(cases):
       n = int(rng.choice(edge)) if rng.random() < 0.5 else int(rng.integers(1, 2600))
-      d = int(rng.integers(1, 41)); m = int(rng.integers(0, 5))
+      d = int(rng.integers(1, 41)); m = int(rng.integers(0, 5)) if rng.random() < 0.7 else int(rng.choice([14, 15, 16, 20]))     # (16 rows in use is where the ride-row tile form ends)
       kind = str(rng.choice(["rbf", "matern52"]))
       dtype = "f32" if (rng.random() < 0.25 and d <= 64 and m <= 3) else "f64"
       W = int(rng.choice([1, 2, 3, 4, 8, 16]))
       opts = {"panel_chain": int(rng.choice([0, 1, 3, 5, 7, 8, 15, 15])), "first_on_panel": int(rng.choice([0, 1, 2])), "lookahead": int(rng.choice([0, 1, 1])),
               "chain_rows": int(rng.choice([0, 8, 80, 1000])), "link_rows": int(rng.choice([0, 16, 256, 4096])), "kbuild_mfma": int(rng.choice([0, 1, 2])),
-              "refine_sym": int(rng.choice([0, 1, 1]))}
+              "refine_sym": int(rng.choice([0, 1, 1])),
+              # the 128-tile update kernel (and with it the diagonal / ride-row tile forms) and the strip solve at sizes that would not reach them by default
+              "small_tile_threshold": int(rng.choice([1, 320])), "tiny_tile_threshold": int(rng.choice([1, 256])), "panel_mode": int(rng.choice([0, 1, 2])),
+              "diag_tiles": int(rng.choice([0, 1, 1])), "ride_tiles": int(rng.choice([0, 1, 1])), "strip_tri": int(rng.choice([0, 1, 1]))}
       X, y, Xs = O.synthetic_problem(n, d, 1000 + case, m=max(m, 1))
       Xs = Xs[:m] if m else None
       ell = float(np.sqrt(d) * 10 ** rng.uniform(-0.5, 0.5)); sn = float(10 ** rng.uniform(-2, 0))
@@ -67,7 +70,9 @@ def run_batches(cases, seed, verbose=True):
       bad = int(rng.integers(0, F)) if (rng.random() < 0.3 and n > 40) else -1
       if bad >= 0:
           Xb[bad % B, n // 2] = Xb[bad % B, n // 3]; sn[bad] = 0.0      # duplicate row + no noise: K~ singular for every fit of that data set with sn~ = 0
-      opts = {"panel_chain": int(rng.choice([0, 1, 3])), "strip_min": int(rng.choice([1, 8, 512])), "first_on_panel": int(rng.choice([0, 1, 2]))}
+      opts = {"panel_chain": int(rng.choice([0, 1, 3])), "strip_min": int(rng.choice([1, 8, 512])), "first_on_panel": int(rng.choice([0, 1, 2])),
+              "small_tile_threshold": int(rng.choice([1, 320])), "strips_after_update": int(rng.choice([0, 1])),
+              "diag_tiles": int(rng.choice([0, 1, 1])), "ride_tiles": int(rng.choice([0, 1, 1])), "strip_tri": int(rng.choice([0, 1, 1]))}
       with GPR(kernel=kind, outer_blocks=W, panel_mode=str(rng.choice(["auto", "strips", "recursive"]))) as gp:
           for k, v in opts.items():
               gp.set_option(k, v)
