@@ -280,7 +280,7 @@ int sigp_profile_reset(sigp_handle* h);
 int sigp_synchronize(sigp_handle* h);
 /* tuning knobs; returns SIGP_BAD_ARG for an unknown name or an invalid value.  Defaults in brackets.
  *   outer_blocks [8]      outer panel width in 128-column blocks (K of the trailing update = 128 x this); left unset, single fits of at most
- *                         32 block columns (n <= 4096) use 16
+ *                         24 block columns (n <= 3072) are one panel
  *   lookahead [1]         factor the next panel on the panel stream while the trailing update runs
  *   schedule [0]          0 right-looking outer panels, 1 left-looking (same factor bit for bit)
  *   panel_mode [2]        rows below a panel's top block: 0 recursion, 1 strip solve, 2 strips when strips x members >= strip_min [512]

@@ -188,6 +188,7 @@ struct sigp_handle {
   int opt_strip_min = 512;
   int opt_diag_tiles = 1;    // symmetric trailing updates: a diagonal tile multiplies the 36 of 64 16 x 16 pairs on or below its diagonal (0 = the whole tile; same lower halves)
   int opt_ride_tiles = 1;    // trailing updates: tiles of the ride-along block row multiply its first 16 rows only when no more are in use (y + <= 15 test points)
+  int opt_strips_f32 = 0;    // fp32 engine: panels may be strip-solved too (panel_mode / strip_min as for fp64)
   int opt_strip_tri = 1;     // strip solves skip the zero tile-slices of the inverse diagonal blocks (0 = multiply the whole 128 x 128 block: same bits, 9 % more MFMAs)
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
@@ -717,13 +718,15 @@ int chain_panel(sigp_handle* h, Slot& s, hipStream_t sp, Real* Mm, long ld, long
 // Every launch covers the same step of all nb factorisations (grid.y / grid.x = member), so launches stay
 // GPU-filling as the trailing matrices shrink and the per-step latency chain is paid once per nb fits.
 // block columns per outer panel
-// (a single fit of at most 32 block columns, unless the caller chose: two panels instead of four -- each panel boundary is a K = 1024 update on
-//  the chain, and the right-looking rides of a 16-column panel still fit beside its diagonal blocks: n = 4096 1.95 vs 2.00 ms, n = 2048 0.835 vs 0.893)
+// (a single fit of at most 24 block columns, unless the caller chose: ONE panel -- no panel boundary (each is a trailing update in series with the
+//  chain), and the right-looking rides of such a panel still fit beside its diagonal blocks: n = 2048 0.670 ms (16) vs 0.715 (8), n = 3072 1.082
+//  (24) vs 1.126 (16) / 1.122 (8).  From there on the rides of the first columns outlast the diagonal block: n = 4096 1.653 (8) / 1.675 (16) / 1.755 (32);
+//  tools/single_sweep.py)
 // (fp32 fits from 192 block columns on: the fp32 update runs its K = 1024 tile in half the time of the fp64 one, so the tile's C read +
 //  write weighs twice as much -- K = 2048 instead: n = 32768 102.95 vs 104.4 ms (12: 103.3, 24: 104.1, 32: 106.3); n = 16384 19.2 vs 19.05: not there)
 inline int outer_width(const sigp_handle* h, int nb, int T, bool f32 = false) {
   if (!h->outer_set && f32 && T >= 192) return 16;             // (a lockstep group of 4 at n = 32768: 97.7 vs 98.6-99.0 ms per fit)
-  return (!h->outer_set && nb == 1 && T <= 32 && (h->opt_panel_chain & 4)) ? 16 : std::max(1, h->opt_outer);
+  return (!h->outer_set && nb == 1 && T <= 24 && (h->opt_panel_chain & 4)) ? std::max(1, T) : std::max(1, h->opt_outer);
 }
 template <typename Real>
 int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, long dinvStride, int nb, long n_pad, bool head_on_panel = false,
@@ -736,7 +739,8 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const bool ride16 = h->opt_ride_tiles && h->opt_diag_tiles && ride_rows <= 16;     // (the RD form lives in the kernel instantiation that has the DG form)
   const int W = outer_width(h, nb, T, std::is_same<Real, float>::value);
   constexpr int diag_lds = diag_lds_bytes<Real>();
-  if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
+  const bool strips_ok = std::is_same<Real, double>::value || h->opt_strips_f32;      // (fp32 panels by strips: an experiment, see docs/EXPERIMENTS.md)
+  if (strips_ok && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
     if (rcm) return rcm;
   }
@@ -857,7 +861,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
   auto use_strips = [&](int J0, int Wp) -> bool {
     const int below = R - (J0 + Wp);             // row blocks under the panel's top block (the ride block is one of them)
-    return std::is_same<Real, double>::value && Wp > 1 && Wp <= MT_W && below > 0 &&
+    return strips_ok && Wp > 1 && Wp <= MT_W && below > 0 &&
            (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
   };
   auto panel_top = [&](int J0, int Wp) -> int {
@@ -1326,6 +1330,7 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "diag_tiles")) { h->opt_diag_tiles = value != 0; return SIGP_OK; }
   if (!strcmp(name, "ride_tiles")) { h->opt_ride_tiles = value != 0; return SIGP_OK; }
+  if (!strcmp(name, "strips_f32")) { h->opt_strips_f32 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_tri")) { h->opt_strip_tri = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
