@@ -188,7 +188,6 @@ struct sigp_handle {
   int opt_strip_min = 512;
   int opt_diag_tiles = 1;    // symmetric trailing updates: a diagonal tile multiplies the 36 of 64 16 x 16 pairs on or below its diagonal (0 = the whole tile; same lower halves)
   int opt_ride_tiles = 1;    // trailing updates: tiles of the ride-along block row multiply its first 16 rows only when no more are in use (y + <= 15 test points)
-  int opt_strips_f32 = 0;    // fp32 engine: panels may be strip-solved too (panel_mode / strip_min as for fp64)
   int opt_strip_tri = 1;     // strip solves skip the zero tile-slices of the inverse diagonal blocks (0 = multiply the whole 128 x 128 block: same bits, 9 % more MFMAs)
   int opt_update_dbg = 0;    // debug library: ablation bits OR-ed into the trailing updates' dbg word (8 no C load, 16 no C store: timing only, results garbage)
   int opt_c_dma = 0;         // trailing update: bring the C tile in by LDS-DMA instead of 64 accumulator-layout loads per lane (A/B switch)
@@ -739,8 +738,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   const bool ride16 = h->opt_ride_tiles && h->opt_diag_tiles && ride_rows <= 16;     // (the RD form lives in the kernel instantiation that has the DG form)
   const int W = outer_width(h, nb, T, std::is_same<Real, float>::value);
   constexpr int diag_lds = diag_lds_bytes<Real>();
-  const bool strips_ok = std::is_same<Real, double>::value || h->opt_strips_f32;      // (fp32 panels by strips: an experiment, see docs/EXPERIMENTS.md)
-  if (strips_ok && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
+  if (std::is_same<Real, double>::value && (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)R * nb >= h->opt_strip_min))) {
     int rcm = slot_ensure_mt(h, s, nb);
     if (rcm) return rcm;
   }
@@ -861,7 +859,7 @@ int potrf_core(sigp_handle* h, Slot& s, Real* M, long matStride, Real* dinvp, lo
   // is not strip-solved); panel_strips = the Mt products + strip kernel for the rows below the top block (no-op otherwise)
   auto use_strips = [&](int J0, int Wp) -> bool {
     const int below = R - (J0 + Wp);             // row blocks under the panel's top block (the ride block is one of them)
-    return strips_ok && Wp > 1 && Wp <= MT_W && below > 0 &&
+    return std::is_same<Real, double>::value && Wp > 1 && Wp <= MT_W && below > 0 &&
            (h->opt_panel_mode == 1 || (h->opt_panel_mode == 2 && (long)below * nb >= h->opt_strip_min));
   };
   auto panel_top = [&](int J0, int Wp) -> int {
@@ -1330,7 +1328,6 @@ int sigp_set_option(sigp_handle* h, const char* name, int64_t value) {
   }
   if (!strcmp(name, "diag_tiles")) { h->opt_diag_tiles = value != 0; return SIGP_OK; }
   if (!strcmp(name, "ride_tiles")) { h->opt_ride_tiles = value != 0; return SIGP_OK; }
-  if (!strcmp(name, "strips_f32")) { h->opt_strips_f32 = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_tri")) { h->opt_strip_tri = value != 0; return SIGP_OK; }
   if (!strcmp(name, "strip_min")) { if (value < 1) return SIGP_BAD_ARG; h->opt_strip_min = (int)value; return SIGP_OK; }
   if (!strcmp(name, "schedule")) { if (value < 0 || value > 1) return SIGP_BAD_ARG; h->opt_schedule = (int)value; return SIGP_OK; }
