@@ -344,7 +344,9 @@ def quote_pmc_traffic(rf, dom, n, d, args):
                     rf["traffic_source"] = ("from profiles/%s_pmc_syrk128.json (rocprofv3 --pmc passes of this command on this kernel code, sha16 %s; NOT this run): bytes per launch = "
                                             "FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE.  %.1f x the algorithmic C bytes: the surplus is the panels' K-slices re-fetched past the 4 MB L2 "
                                             "(served by the Infinity Cache).  Closed by measurement: XCD-chunked tile walks cut the fetch to 4.9-6.3 GB per launch and the clock does not rise "
-                                            "(MFMA-bound kernel, pipe busy %.2f): fits/s fell 1 %% (profiles/r04_syrk128_traffic_vs_clock.txt)"
+                                            "(MFMA-bound kernel, pipe busy %.2f): fits/s fell 1 %% (profiles/r04_syrk128_traffic_vs_clock.txt).  17.2 GB of it before the diagonal / ride-row tile forms: "
+                                            "those tiles are shorter and shift the phase of the tiles that share a B block through L2 (flag test: 16.7 GB with the forms off); a walk that puts "
+                                            "them at the end of the launch restores 19.3 GB and changes fits/s by nothing (docs/EXPERIMENTS.md)"
                                             % (rnd, pm["kernel_code_sha16"], pm["traffic_bytes_per_launch"] / (dom["bytes"] / dom["launches"]), pm.get("mfma_pipe_busy_fraction", 0.0)))
                 else:
                     rf["traffic_source"] = ("profiles/%s_pmc_syrk128.json was collected from other kernel code (sha16 %s, now %s): not quoted"
